@@ -1,0 +1,163 @@
+/*
+ * sibrar_hip.h — C ABI of libsibrar_hip.so, the MI355X (gfx950) engine for the SiBraR SingleBranchNet hot path.
+ *
+ * Conventions:
+ *   - plain C: raw DEVICE pointers (e.g. torch's tensor.data_ptr()), explicit sizes / leading dimensions in ELEMENTS,
+ *     scalar hyper-parameters, and a `void* stream` that is a hipStream_t (NULL = default stream);
+ *   - no ownership transfer: every buffer (parameters, gradients, activations, workspaces) is allocated and freed by
+ *     the caller; kernels are stateless, asynchronous on the given stream and re-entrant per stream;
+ *   - return value: 0 = ok, non-zero = error; sbr_last_error() returns the message of the calling thread's last error;
+ *   - row-index arrays (`*_idx`, `rows`, `slots`) are int32 device arrays, entity ids are int64 (torch.long) as the
+ *     reference's loaders produce them (data/dataloader.py:196-198); NULL index array = identity.
+ *
+ * The reference (Tigxy/SiBraR---Single-Branch-Recommender) has no native code and therefore no FFI: each entry point
+ * below names the PyTorch call site(s) of the reference that it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ */
+#ifndef SIBRAR_HIP_H
+#define SIBRAR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes — modules/polylinear.py:5-10 (ACTIVATION_FN_MAP) */
+#define SBR_ACT_NONE 0
+#define SBR_ACT_RELU 1
+#define SBR_ACT_TANH 2
+#define SBR_ACT_SIGMOID 3
+#define SBR_ACT_SELU 4
+
+/* recommendation-loss kinds — train/rec_losses.py:116-119 (RecommenderSystemLossesEnum) */
+#define SBR_LOSS_BCE 0
+#define SBR_LOSS_BPR 1
+#define SBR_LOSS_SAMPLED_SOFTMAX 2
+
+const char* sbr_last_error(void);
+int sbr_abi_version(void);
+
+/* ---- dense products on the matrix cores (fp32 in / fp32 accumulate, v_mfma_f32_32x32x2_f32) -------------------------
+ * mode 0 (NT): C[ci(m), n] = act(sum_k A[ai(m), k] * B[n, k] + bias[n])     nn.Linear forward — modules/polylinear.py:51,
+ *              the modality projectors algorithms/sgd_alg.py:1342-1357 with the row gather of sgd_alg.py:1960-1974 fused
+ *              in, and the all-pairs scorer einsum('be,ce->bc') algorithms/sgd_alg.py:2109 / eval/eval.py:217.
+ * mode 1 (NN): C[m, n] = sum_k A[ai(m), k] * B[k, n]                        autograd of nn.Linear w.r.t. its input.
+ * mode 2 (TN): C[m, n] += sum_k A[ak(k), m] * B[bk(k), n]                   autograd of nn.Linear w.r.t. its weight; split
+ *              over k with float atomics, so C must be zero-initialised and accumulate_atomic must be 1.
+ * a_idx / b_idx / c_idx: optional int32 row maps (NULL = identity). */
+int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx,
+                 const float* bias, float* C, long ldc, const int* c_idx, int M, int N, int K, int act,
+                 int accumulate_atomic, void* stream);
+
+/* ---- index plumbing ----------------------------------------------------------------------------------------------------
+ * rows_out[j] = rowmap_seg(j)[ idx[slots[j] / k] ] for the concatenated per-modality slot lists (segment s covers
+ * [seg_offsets[s], seg_offsets[s+1])): the id -> row lookup of Feature.__getitem__ (data/Feature.py:146) on the
+ * repeat_interleave'd index vector of algorithms/sgd_alg.py:1944-1946. rowmaps is a HOST array of n_seg device pointers
+ * (NULL entry = identity). err_flag (device int) is set to 1 when an id is absent from a feature's split. */
+int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg, const int* seg_offsets,
+                     const int* const* rowmaps, int* rows_out, int* err_flag, void* stream);
+
+/* nn.Embedding forward — algorithms/sgd_alg.py:1331,1386: out[oi(j), :] = W[rows[j], :] */
+int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx, long n, int D,
+                    void* stream);
+/* its dense gradient: dW[rows[j], :] += dOut[ii(j), :] (dW zero-initialised by the caller) */
+int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW, long ldw, long n, int D,
+                         void* stream);
+
+/* nn.EmbeddingBag(mode='mean', padding_idx=pad) over padded tag lists — algorithms/sgd_alg.py:1336-1337, 1383-1386;
+ * data/Feature.py:254-255. tags: [n_table_rows, T] int32. */
+int sbr_bag_mean_fwd(const float* W, long ldw, const int* tags, int T, int pad, const int* rows, float* out, long ldo,
+                     const int* out_idx, long n, int D, void* stream);
+int sbr_bag_mean_bwd(const float* dOut, long ldo, const int* in_idx, const int* tags, int T, int pad, const int* rows,
+                     float* dW, long ldw, long n, int D, void* stream);
+
+/* Linear over the CSR "interactions" modality without densifying — replaces data/Feature.py:149-150 (.toarray()) +
+ * algorithms/sgd_alg.py:1380 (x.float()) + modules/polylinear.py:51. Wt is the projector weight stored column-major
+ * (row c of Wt = column c of the [C, n_cols] nn.Linear weight). vals may be NULL (all ones). */
+int sbr_csr_project_fwd(const long* indptr, const int* indices, const float* vals, const float* Wt, long ldw,
+                        const float* bias, const int* rows, float* out, long ldo, const int* out_idx, long n, int C, int act,
+                        void* stream);
+int sbr_csr_project_bwd(const long* indptr, const int* indices, const float* vals, const float* dZ, long ldz, const int* rows,
+                        float* dWt, long ldw, long n, int C, void* stream);
+
+/* dZ[j, :] = dY[ii(j), :] * act'(Y[ii(j), :]) — autograd of the activations of modules/polylinear.py:63-72 */
+int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz, long n, int C,
+                        int act, void* stream);
+/* out[c] = sum_j X[j, c] (bias gradients). workspace: C doubles. */
+int sbr_colsum(const float* X, long ld, long n, int C, float* out, double* workspace, void* stream);
+
+/* F.normalize(p=2, dim=-1, eps) — algorithms/sgd_alg.py:1873-1874 */
+int sbr_l2norm_fwd(const float* X, float* Y, float* inv_norm, long n, int C, float eps, void* stream);
+int sbr_l2norm_bwd(const float* dY, const float* Y, const float* inv_norm, float* dX, long n, int C, float eps, void* stream);
+
+/* nn.Dropout(p) — algorithms/sgd_alg.py:1815, modules/polylinear.py:48; counter-based mask from (seed, element index),
+ * the same call maps dY -> dX in the backward pass. */
+int sbr_dropout(const float* X, float* Y, long total, float p, unsigned long long seed, void* stream);
+
+/* aggregation over the k sampled modalities — algorithms/sgd_alg.py:27-31, 1861. mode 0 mean, 1 max. */
+int sbr_aggregate_fwd(const float* E, float* out, unsigned char* argmax, long S, int k, int D, int mode, void* stream);
+int sbr_aggregate_bwd(const float* dOut, const unsigned char* argmax, float* dE, long S, int k, int D, int mode, void* stream);
+
+/* training scorer einsum('be,bce->bc') — algorithms/sgd_alg.py:2114 */
+int sbr_score_dot_fwd(const float* U, const float* I, float* out, long B, int N, int D, void* stream);
+int sbr_score_dot_bwd(const float* G, const float* U, const float* I, float* dU, float* dI, long B, int N, int D, void* stream);
+/* SGDBaseline — algorithms/sgd_alg.py:110-119 */
+int sbr_bias_score_fwd(const float* user_bias, const float* item_bias, const float* global_bias, const long* u, const long* i,
+                       float* out, long B, int N, void* stream);
+
+/* ---- BatchNorm1d (+ fused activation) — modules/polylinear.py:61,68; algorithms/sgd_alg.py:1837 ---------------------------
+ * ws: 2*D doubles of workspace. running_mean/var/num_batches_tracked may be NULL. */
+int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias, float* running_mean,
+                     float* running_var, long* num_batches_tracked, float* save_mean, float* save_rstd, double* ws, float eps,
+                     float momentum, int act, void* stream);
+int sbr_bn_eval_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias, const float* running_mean,
+                    const float* running_var, float eps, int act, void* stream);
+int sbr_bn_train_bwd(const float* dY, const float* Y, const float* X, float* dX, long n, int D, const float* weight,
+                     const float* save_mean, const float* save_rstd, float* dWeight, float* dBias, double* ws, int act,
+                     void* stream);
+
+/* ---- losses ----------------------------------------------------------------------------------------------------------------
+ * RecBinaryCrossEntropy / RecBayesianPersonalizedRankingLoss / RecSampledSoftmaxLoss .compute_loss —
+ * train/rec_losses.py:43-58, 63-83, 88-113. labels: float64 [B, N] (unused for sampled softmax). scale = 1/count for
+ * aggregator 'mean' (count = B*N bce, B*(N-1) bpr, B sampled softmax), 1 for 'sum'. shift = log(n_items / n_neg) for the
+ * 'uniform' strategy of sampled softmax, else 0. loss_out: one double. */
+int sbr_rec_loss_fwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                     double* loss_out, void* stream);
+int sbr_rec_loss_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                     const void* grad_out, int grad_out_is_double, float* dlogits, void* stream);
+
+/* InfoNCE.forward — train/regularization_losses.py:14-43, called from algorithms/sgd_alg.py:1989 on e[..., 0, :] and
+ * e[..., 1, :]. G groups of N rows, row stride ld; N <= sbr_infonce_max_n(). scale = 1/(G*N) for 'mean'. */
+int sbr_infonce_max_n(void);
+int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale, double* loss_out,
+                    void* stream);
+int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                    const float* grad_out, float* dA, float* dB, long ldg, void* stream);
+
+/* ---- dense optimizers over one flat fp32 buffer — train/trainer.py:62-68, 222 ---------------------------------------------
+ * kind 0 = torch.optim.AdamW, 1 = torch.optim.Adam; step is the 1-based step count. */
+int sbr_adam_step(int kind, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                  double wd, long step, void* stream);
+int sbr_adagrad_step(float* p, const float* g, float* state_sum, long n, double lr, double eps, double wd, void* stream);
+
+/* ---- full-catalogue evaluation — eval/eval.py:205-222 ------------------------------------------------------------------------
+ * exclusion mask out[b, excl(u_b)] = -inf (eval/eval.py:219-220) from the CSR `exclude_data` (data/dataset.py:416-438) */
+int sbr_mask_scores(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices, long Bu,
+                    void* stream);
+/* exact per-row top-k, sorted by (score desc, index asc) — torch.topk at eval/eval.py:320 and inside rmet.calculate */
+int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k, float* out_val, int* out_idx, void* stream);
+/* NDCG / recall / precision @ ks from top-k indices and CSR labels — eval/metrics.py:4-105. out: [3, n_ks, Bu]. */
+int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const long* label_indptr, const int* label_indices,
+                     long Bu, const int* ks, int n_ks, float* out, void* stream);
+/* fused scorer: fp16 MFMA  U[Bu, D] x I[I_s, D]^T  with the exclusion mask and the running per-user top-k kept on chip; the
+ * [Bu, I_s] score matrix is never written (BASELINE config 5). See csrc/score_topk_f16.hip. */
+int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
+                       const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val, int* out_idx,
+                       void* workspace, long workspace_bytes, void* stream);
+long sbr_score_topk_f16_workspace(long Bu, int I, int k);
+/* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
+int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

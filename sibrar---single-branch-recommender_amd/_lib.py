@@ -1,0 +1,89 @@
+"""ctypes binding of libsibrar_hip.so — the C-ABI boundary of the engine (include/sibrar_hip.h).
+
+The prototypes are parsed from the header itself so that the binding and the ABI cannot drift apart. There is NO
+CPU fallback: if the shared library is missing, ``lib()`` raises, and every op of this package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsibrar_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'sibrar_hip.h')
+
+
+class SibrarHipError(RuntimeError):
+    pass
+
+
+_CTYPES = {
+    'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
+    'unsigned long long': ctypes.c_ulonglong,
+}
+
+
+def parse_header(path: str = HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every prototype declared in the header."""
+    text = open(path).read()
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', ' ', text)
+    text = re.sub(r'#[^\n]*', ' ', text)
+    protos = {}
+    for m in re.finditer(r'([A-Za-z_][\w\s\*]*?)\b(sbr_\w+)\s*\(([^;{}]*?)\)\s*;', text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        ret = ret.replace('extern "C"', '').strip()
+        restype = ctypes.c_char_p if '*' in ret else _CTYPES.get(ret.replace('const', '').strip(), ctypes.c_int)
+        argtypes, argnames = [], []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                mm = re.match(r'(.*?)(\w+)$', a)
+                typ, nm = mm.group(1).strip(), mm.group(2)
+                if '*' in typ:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[typ.replace('const', '').strip()])
+                argnames.append(nm)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SibrarHipError(
+                f'{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C '
+                f'"{os.path.join(_HERE, "csrc")}"`). This package has no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes, _) in parse_header().items():
+            fn = getattr(handle, name)        # AttributeError here == the library does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = handle
+    return _LIB
+
+
+def check(status: int):
+    if status != 0:
+        raise SibrarHipError(lib().sbr_last_error().decode())
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise SibrarHipError on a non-zero status."""
+    check(getattr(lib(), name)(*args))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,167 @@
+// BatchNorm1d over the row dimension of an [R, D] activation matrix, fused with the following activation
+// (modules/polylinear.py:61-65, 68; algorithms/sgd_alg.py:1837). torch defaults: eps 1e-5, momentum 0.1, the running
+// variance is the unbiased batch variance, normalisation uses the biased one.
+//
+// Train forward:  pass 1 column sums (sum x, sum x^2) in double -> ws[2*D] ; pass 2 normalise + affine + activation.
+// Train backward: pass 1 column sums of dz and dz*xhat        -> ws[2*D] ; pass 2 dx = w*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)).
+// HBM-bound: forward reads X twice and writes Y once (12 B/element), backward reads X, Y, dY twice and writes dX.
+#include "common.h"
+
+// grid: (row chunks, column groups of 64); block 256 = 4 row lanes x 64 columns
+__global__ void bn_stats_kernel(const float* __restrict__ X, long n, int D, double* __restrict__ ws) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double s = 0.0, ss = 0.0;
+  if (c < D)
+    for (long j = blockIdx.x * 4L + rg; j < n; j += gridDim.x * 4L) {
+      const double v = (double)X[j * D + c];
+      s += v;
+      ss += v * v;
+    }
+  __shared__ double sm[2][256];
+  sm[0][threadIdx.x] = s;
+  sm[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (rg == 0 && c < D) {
+    const int t = threadIdx.x;
+    atomicAdd(&ws[c], sm[0][t] + sm[0][t + 64] + sm[0][t + 128] + sm[0][t + 192]);
+    atomicAdd(&ws[D + c], sm[1][t] + sm[1][t + 64] + sm[1][t + 128] + sm[1][t + 192]);
+  }
+}
+
+// one thread per column: batch mean / rstd, running-stat update
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, long n, int D, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long* __restrict__ num_batches) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches) num_batches[0] += 1;
+  if (c >= D) return;
+  const double m = ws[c] / (double)n;
+  double var = ws[D + c] / (double)n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ X, float* __restrict__ Y, long n, int D,
+                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ w, const float* __restrict__ b, int act) {
+  const long total = n * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % D);
+    Y[e] = sbr_act((X[e] - mean[c]) * rstd[c] * w[c] + b[c], act);
+  }
+}
+
+// eval mode: running statistics
+__global__ void bn_eval_kernel(const float* __restrict__ X, float* __restrict__ Y, long n, int D,
+                               const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ w,
+                               const float* __restrict__ b, float eps, int act) {
+  const long total = n * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % D);
+    Y[e] = sbr_act((X[e] - rm[c]) / sqrtf(rv[c] + eps) * w[c] + b[c], act);
+  }
+}
+
+static int grid1d(long total) {
+  int b = sbr_cdiv(total, 256);
+  return b > 4096 ? 4096 : (b < 1 ? 1 : b);
+}
+
+// workspace ws: 2*D doubles
+extern "C" int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
+                                float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
+                                float* save_rstd, double* ws, float eps, float momentum, int act, void* stream) {
+  SBR_REQUIRE(X && Y && weight && bias && save_mean && save_rstd && ws, "sbr_bn_train_fwd: null operand");
+  SBR_REQUIRE(n >= 1, "sbr_bn_train_fwd: BatchNorm needs at least one row");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * D, s) != hipSuccess) { sbr_set_error("sbr_bn_train_fwd: memset failed"); return SBR_ERR_HIP; }
+  int bx = sbr_cdiv(n, 64);
+  if (bx > 512) bx = 512;
+  bn_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(X, n, D, ws);
+  SBR_CHECK_LAUNCH("sbr_bn_train_fwd/stats");
+  bn_finalize_kernel<<<sbr_cdiv(D, 256), 256, 0, s>>>(ws, n, D, eps, momentum, save_mean, save_rstd, running_mean,
+                                                      running_var, num_batches_tracked);
+  SBR_CHECK_LAUNCH("sbr_bn_train_fwd/finalize");
+  bn_apply_kernel<<<grid1d(n * D), 256, 0, s>>>(X, Y, n, D, save_mean, save_rstd, weight, bias, act);
+  SBR_CHECK_LAUNCH("sbr_bn_train_fwd/apply");
+  return SBR_OK;
+}
+
+extern "C" int sbr_bn_eval_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
+                               const float* running_mean, const float* running_var, float eps, int act, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y && weight && bias && running_mean && running_var, "sbr_bn_eval_fwd: null operand");
+  bn_eval_kernel<<<grid1d(n * D), 256, 0, (hipStream_t)stream>>>(X, Y, n, D, running_mean, running_var, weight, bias, eps, act);
+  SBR_CHECK_LAUNCH("sbr_bn_eval_fwd");
+  return SBR_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// dz = dY * act'(Y);  ws[c] = sum dz ; ws[D + c] = sum dz * xhat
+__global__ void bn_bwd_stats_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ X,
+                                    long n, int D, const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                    double* __restrict__ ws) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double s = 0.0, sx = 0.0;
+  if (c < D) {
+    const float m = mean[c], r = rstd[c];
+    for (long j = blockIdx.x * 4L + rg; j < n; j += gridDim.x * 4L) {
+      const long e = j * D + c;
+      const float dz = dY[e] * sbr_act_grad_from_out(Y[e], act);
+      s += (double)dz;
+      sx += (double)(dz * ((X[e] - m) * r));
+    }
+  }
+  __shared__ double sm[2][256];
+  sm[0][threadIdx.x] = s;
+  sm[1][threadIdx.x] = sx;
+  __syncthreads();
+  if (rg == 0 && c < D) {
+    const int t = threadIdx.x;
+    atomicAdd(&ws[c], sm[0][t] + sm[0][t + 64] + sm[0][t + 128] + sm[0][t + 192]);
+    atomicAdd(&ws[D + c], sm[1][t] + sm[1][t + 64] + sm[1][t + 128] + sm[1][t + 192]);
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ X,
+                                    float* __restrict__ dX, long n, int D, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ w, int act,
+                                    const double* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dB) {
+  const long total = n * D;
+  const double inv_n = 1.0 / (double)n;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % D);
+    const float dz = dY[e] * sbr_act_grad_from_out(Y[e], act);
+    const float xhat = (X[e] - mean[c]) * rstd[c];
+    const float mdz = (float)(ws[c] * inv_n), mdzx = (float)(ws[D + c] * inv_n);
+    dX[e] = w[c] * rstd[c] * (dz - mdz - xhat * mdzx);
+    if (e < D) {       // first row's threads also publish the affine gradients
+      dB[c] = (float)ws[c];
+      dW[c] = (float)ws[D + c];
+    }
+  }
+}
+
+extern "C" int sbr_bn_train_bwd(const float* dY, const float* Y, const float* X, float* dX, long n, int D,
+                                const float* weight, const float* save_mean, const float* save_rstd, float* dWeight,
+                                float* dBias, double* ws, int act, void* stream) {
+  SBR_REQUIRE(dY && Y && X && dX && weight && save_mean && save_rstd && dWeight && dBias && ws, "sbr_bn_train_bwd: null operand");
+  SBR_REQUIRE(n >= 1, "sbr_bn_train_bwd: empty batch");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * D, s) != hipSuccess) { sbr_set_error("sbr_bn_train_bwd: memset failed"); return SBR_ERR_HIP; }
+  int bx = sbr_cdiv(n, 64);
+  if (bx > 512) bx = 512;
+  bn_bwd_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(dY, Y, X, n, D, save_mean, save_rstd, act, ws);
+  SBR_CHECK_LAUNCH("sbr_bn_train_bwd/stats");
+  bn_bwd_apply_kernel<<<grid1d(n * D), 256, 0, s>>>(dY, Y, X, dX, n, D, save_mean, save_rstd, weight, act, ws, dWeight, dBias);
+  SBR_CHECK_LAUNCH("sbr_bn_train_bwd/apply");
+  return SBR_OK;
+}

@@ -1,0 +1,292 @@
+// fp32 GEMM family on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit an
+// fmaf chain, so results stay within fp32 rounding of the reference's CPU matmuls).
+//
+// One kernel template serves the three products of the SingleBranchNet hot path:
+//   NT  C[m,n] = act(sum_k A[ai(m),k] * B[n,k] + bias[n])  -> C[ci(m),n]      Linear forward  (polylinear.py:51)
+//                                                                             + the scorer u @ i^T (sgd_alg.py:2109)
+//   NN  C[m,n] = sum_k A[ai(m),k] * B[k,n]                                    dX = dZ @ W
+//   TN  C[m,n] = sum_k A[ak(k),m] * B[bk(k),n]   (split-K, atomic add)        dW = dZ^T @ X
+// ai/ci/ak/bk are optional int32 row-index arrays: the per-modality row gathers of
+// SingleBranchNetEntity._get_modality_embeddings (sgd_alg.py:1934-1978) and the scatter back into the
+// [R, C] embedding matrix are fused into the tile loads / stores instead of materialising gathered copies.
+//
+// Tiling: 256 threads = 4 wavefronts of 64; each wave owns MI x NI tiles of 32x32 (16 accumulator VGPRs each).
+// K is consumed in BK=32 slabs staged through LDS from registers (global loads for slab t+1 are issued before the
+// MFMAs of slab t). Within each 8-wide k group lane-half h supplies k = 4h + s to MFMA step s, so one 16-byte LDS
+// read feeds four MFMAs.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A; long lda; const int* a_idx;
+  const float* B; long ldb; const int* b_idx;
+  const float* bias;
+  float* C; long ldc; const int* c_idx;
+  int M, N, K;
+  int act;
+  int k_chunk;
+  int atomic;
+  int vecA, vecB;
+  int mt, nt;
+};
+
+#define BK 32
+
+template <int ROWS, bool KM>
+struct TileGeom {
+  // floats per thread = ROWS*BK/256
+  static constexpr int P = ROWS * BK / (4 * 256);   // float4 per thread
+  static constexpr int LD = KM ? (ROWS + 4) : (BK + 4);
+  static constexpr int SIZE = KM ? BK * (ROWS + 4) : ROWS * (BK + 4);
+};
+
+// ---- global -> register loads -------------------------------------------------------------------------------
+template <int ROWS, int P>
+__device__ __forceinline__ void load_mk(float4 (&r)[P], const float* __restrict__ src, const long (&rowoff)[P],
+                                        int kbase, int kend, int vec, int t) {
+  const int kc = (t & 7) * 4;
+  const int gk = kbase + kc;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rowoff[p] >= 0) {
+      const float* q = src + rowoff[p] + gk;
+      if (vec && gk + 3 < kend) {
+        v = *reinterpret_cast<const float4*>(q);
+      } else {
+        if (gk < kend) v.x = q[0];
+        if (gk + 1 < kend) v.y = q[1];
+        if (gk + 2 < kend) v.z = q[2];
+        if (gk + 3 < kend) v.w = q[3];
+      }
+    }
+    r[p] = v;
+  }
+}
+
+template <int ROWS, int P>
+__device__ __forceinline__ void load_km(float4 (&r)[P], const float* __restrict__ src, long ld,
+                                        const int* __restrict__ kidx, int row0, int nrows, int kbase, int kend,
+                                        int vec, int t) {
+  constexpr int TPR = ROWS / 4;          // threads per k-row
+  constexpr int RPP = 256 / TPR;         // k-rows per pass
+  const int c = row0 + (t % TPR) * 4;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int gk = kbase + t / TPR + RPP * p;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gk < kend && c < nrows) {
+      const long kr = kidx ? (long)kidx[gk] : (long)gk;
+      const float* q = src + kr * ld + c;
+      if (vec && c + 3 < nrows) {
+        v = *reinterpret_cast<const float4*>(q);
+      } else {
+        v.x = q[0];
+        if (c + 1 < nrows) v.y = q[1];
+        if (c + 2 < nrows) v.z = q[2];
+        if (c + 3 < nrows) v.w = q[3];
+      }
+    }
+    r[p] = v;
+  }
+}
+
+// ---- register -> LDS ---------------------------------------------------------------------------------------------
+template <int ROWS, bool KM, int P>
+__device__ __forceinline__ void store_lds(float* __restrict__ s, const float4 (&r)[P], int t) {
+  if constexpr (!KM) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int row = (t >> 3) + 32 * p;
+      *reinterpret_cast<float4*>(&s[row * (BK + 4) + (t & 7) * 4]) = r[p];
+    }
+  } else {
+    constexpr int TPR = ROWS / 4;
+    constexpr int RPP = 256 / TPR;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int kr = t / TPR + RPP * p;
+      *reinterpret_cast<float4*>(&s[kr * (ROWS + 4) + (t % TPR) * 4]) = r[p];
+    }
+  }
+}
+
+// ---- LDS -> MFMA operand fragments ------------------------------------------------------------------------------------
+template <int ROWS, bool KM>
+__device__ __forceinline__ float4 read_frag(const float* __restrict__ s, int row, int kq, int half) {
+  if constexpr (!KM) {
+    return *reinterpret_cast<const float4*>(&s[row * (BK + 4) + kq * 8 + 4 * half]);
+  } else {
+    const float* q = &s[(kq * 8 + 4 * half) * (ROWS + 4) + row];
+    return make_float4(q[0], q[ROWS + 4], q[2 * (ROWS + 4)], q[3 * (ROWS + 4)]);
+  }
+}
+
+template <int WM, int WN, int MI, int NI, bool A_KM, bool B_KN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BM = WM * MI * 32;
+  constexpr int BN = WN * NI * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  using GA = TileGeom<BM, A_KM>;
+  using GB = TileGeom<BN, B_KN>;
+  __shared__ __attribute__((aligned(16))) float smem[GA::SIZE + GB::SIZE];
+  float* As = smem;
+  float* Bs = smem + GA::SIZE;
+
+  // XCD-aware tile order: the nt column tiles of one row panel run on the same XCD (block ids b and b+8 share an
+  // XCD) so that the gathered A rows are fetched into one L2 only. Speed only; any mapping is correct.
+  int mt_i, nt_i;
+  {
+    const int b = blockIdx.x;
+    const int x = b & 7, j = b >> 3;
+    const int cnt = (g.mt - x + 7) >> 3;           // panels owned by this XCD group
+    if (j >= cnt * g.nt) return;
+    mt_i = x + 8 * (j / g.nt);
+    nt_i = j % g.nt;
+  }
+  const int m0 = mt_i * BM, n0 = nt_i * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int kstart = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kstart + g.k_chunk);
+
+  long a_off[GA::P];
+  long b_off[GB::P];
+  if constexpr (!A_KM) {
+#pragma unroll
+    for (int p = 0; p < GA::P; ++p) {
+      const int gm = m0 + (t >> 3) + 32 * p;
+      a_off[p] = gm < g.M ? (g.a_idx ? (long)g.a_idx[gm] : (long)gm) * g.lda : -1;
+    }
+  }
+  if constexpr (!B_KN) {
+#pragma unroll
+    for (int p = 0; p < GB::P; ++p) {
+      const int gn = n0 + (t >> 3) + 32 * p;
+      b_off[p] = gn < g.N ? (g.b_idx ? (long)g.b_idx[gn] : (long)gn) * g.ldb : -1;
+    }
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[GA::P], rb[GB::P];
+  auto fetch = [&](int kbase) {
+    if constexpr (!A_KM) load_mk<BM>(ra, g.A, a_off, kbase, kend, g.vecA, t);
+    else load_km<BM>(ra, g.A, g.lda, g.a_idx, m0, g.M, kbase, kend, g.vecA, t);
+    if constexpr (!B_KN) load_mk<BN>(rb, g.B, b_off, kbase, kend, g.vecB, t);
+    else load_km<BN>(rb, g.B, g.ldb, g.b_idx, n0, g.N, kbase, kend, g.vecB, t);
+  };
+
+  if (kstart < kend) fetch(kstart);
+  for (int kbase = kstart; kbase < kend; kbase += BK) {
+    __syncthreads();                       // previous slab fully consumed
+    store_lds<BM, A_KM>(As, ra, t);
+    store_lds<BN, B_KN>(Bs, rb, t);
+    __syncthreads();
+    if (kbase + BK < kend) fetch(kbase + BK);   // in flight under the MFMAs below
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) {
+      float4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag<BM, A_KM>(As, (wm * MI + i) * 32 + l31, kq, half);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = read_frag<BN, B_KN>(Bs, (wn * NI + j) * 32 + l31, kq, half);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: accumulator register r of a 32x32 tile is row (r&3) + 8*(r>>2) + 4*half, column lane&31
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gm = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (gm >= g.M) continue;
+      const long crow = (g.c_idx ? (long)g.c_idx[gm] : (long)gm) * g.ldc;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int gn = n0 + (wn * NI + j) * 32 + l31;
+        if (gn >= g.N) continue;
+        float v = acc[i][j][r];
+        if (g.atomic) {
+          if (g.bias && blockIdx.z == 0) v += g.bias[gn];
+          atomicAdd(&g.C[crow + gn], v);
+        } else {
+          if (g.bias) v += g.bias[gn];
+          g.C[crow + gn] = sbr_act(v, g.act);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int MI, int NI, bool A_KM, bool B_KN>
+static int launch(GemmArgs& g, int splits, hipStream_t s) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  g.mt = sbr_cdiv(g.M, BM);
+  g.nt = sbr_cdiv(g.N, BN);
+  const int per_xcd = sbr_cdiv(g.mt, 8) * g.nt;
+  dim3 grid(per_xcd * 8, 1, splits);
+  gemm_f32_kernel<WM, WN, MI, NI, A_KM, B_KN><<<grid, 256, 0, s>>>(g);
+  SBR_CHECK_LAUNCH("sbr_gemm_f32");
+  return SBR_OK;
+}
+
+static inline int aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+// mode: 0 = NT, 1 = NN, 2 = TN
+extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const float* B, long ldb,
+                            const int* b_idx, const float* bias, float* C, long ldc, const int* c_idx, int M, int N,
+                            int K, int act, int accumulate_atomic, void* stream) {
+  SBR_REQUIRE(mode >= 0 && mode <= 2, "sbr_gemm_f32: bad mode %d", mode);
+  SBR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sbr_gemm_f32: negative size");
+  if (M == 0 || N == 0) return SBR_OK;
+  SBR_REQUIRE(A && B && C, "sbr_gemm_f32: null operand");
+  SBR_REQUIRE(!(accumulate_atomic && act != SBR_ACT_NONE), "sbr_gemm_f32: activation with atomic accumulate");
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.bias = bias;
+  g.C = C; g.ldc = ldc; g.c_idx = c_idx; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.vecA = aligned16(A, lda); g.vecB = aligned16(B, ldb);
+  g.atomic = accumulate_atomic;
+  g.k_chunk = ((K + BK - 1) / BK) * BK;
+  if (g.k_chunk == 0) g.k_chunk = BK;
+  int splits = 1;
+  if (mode == 2) {
+    // dW-shaped: small M x N output, K = number of rows. Split K so that >= ~512 workgroups exist; partial sums are
+    // combined with float atomics into the zero-initialised output (the caller zeroes C).
+    SBR_REQUIRE(accumulate_atomic, "sbr_gemm_f32: TN mode requires a zero-initialised C and accumulate_atomic=1");
+    const int tiles = sbr_cdiv(M, 64) * sbr_cdiv(N, 128);
+    int want = (1024 + tiles - 1) / tiles;
+    int max_splits = sbr_cdiv(K, 256);
+    splits = want < max_splits ? want : max_splits;
+    if (splits < 1) splits = 1;
+    g.k_chunk = sbr_cdiv(sbr_cdiv(K, splits), BK) * BK;
+    splits = sbr_cdiv(K, g.k_chunk);
+    return launch<2, 2, 1, 2, true, true>(g, splits, s);          // 64 x 128 tile
+  }
+  if (mode == 1) {
+    if (N <= 64) return launch<4, 1, 1, 2, false, true>(g, 1, s);  // 128 x 64
+    return launch<2, 2, 2, 2, false, true>(g, 1, s);               // 128 x 128
+  }
+  if (N <= 64) return launch<4, 1, 1, 2, false, false>(g, 1, s);
+  return launch<2, 2, 2, 2, false, false>(g, 1, s);
+}

@@ -1,0 +1,202 @@
+// Recommendation losses (train/rec_losses.py) and the InfoNCE regulariser (train/regularization_losses.py),
+// forward and gradient w.r.t. the logits / embeddings.
+//
+// dtype notes that follow the reference: labels are float64 (data/dataloader.py:196), therefore BCE and BPR evaluate
+// BCEWithLogits in float64 and return a float64 scalar; sampled-softmax and InfoNCE stay in float32 (we accumulate their
+// sums in double and round once).
+#include "common.h"
+
+#define LOSS_BCE 0
+#define LOSS_BPR 1
+#define LOSS_SSM 2
+
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+  v = sbr_wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+  return t;   // valid on thread 0
+}
+
+// softplus-form BCE-with-logits term: max(x,0) - x*y + log1p(exp(-|x|))
+__device__ __forceinline__ double bce_term(double x, double y) { return fmax(x, 0.0) - x * y + log1p(exp(-fabs(x))); }
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// one thread per batch row
+template <bool BWD>
+__global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, const double* __restrict__ labels, long B, int N,
+                                double scale, float shift, double* __restrict__ loss_out, const void* __restrict__ gout,
+                                int gout_is_double, float* __restrict__ dlogits) {
+  const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  double up = 1.0;
+  if (BWD) up = (gout_is_double ? ((const double*)gout)[0] : (double)((const float*)gout)[0]) * scale;
+  if (b < B) {
+    const float* x = logits + b * N;
+    if (kind == LOSS_BCE) {
+      for (int j = 0; j < N; ++j) {
+        const double xv = (double)x[j], y = labels[b * N + j];
+        if (!BWD) acc += bce_term(xv, y);
+        else dlogits[b * N + j] = (float)(up * (sigmoid_d(xv) - y));
+      }
+    } else if (kind == LOSS_BPR) {
+      // rec_losses.py:73-81: diff = pos - neg (float32), target = label of the positive column
+      const double y = labels[b * N];
+      double gpos = 0.0;
+      for (int j = 1; j < N; ++j) {
+        const double d = (double)(x[0] - x[j]);
+        if (!BWD) acc += bce_term(d, y);
+        else {
+          const double gd = up * (sigmoid_d(d) - y);
+          gpos += gd;
+          dlogits[b * N + j] = (float)(-gd);
+        }
+      }
+      if (BWD) dlogits[b * N] = (float)gpos;
+    } else {
+      // rec_losses.py:101-108: -x_pos + logsumexp(x) with the negatives shifted by log(n_items / n_neg) ('uniform')
+      float mx = x[0];
+      for (int j = 1; j < N; ++j) mx = fmaxf(mx, x[j] + shift);
+      float se = expf(x[0] - mx);
+      for (int j = 1; j < N; ++j) se += expf(x[j] + shift - mx);
+      const float lse = mx + logf(se);
+      if (!BWD) acc += (double)(lse - x[0]);
+      else {
+        for (int j = 0; j < N; ++j) {
+          const float p = expf(x[j] + (j ? shift : 0.f) - lse);
+          dlogits[b * N + j] = (float)(up * (double)(p - (j == 0 ? 1.f : 0.f)));
+        }
+      }
+    }
+  }
+  if (!BWD) {
+    __shared__ double sm[4];
+    const double t = block_sum_d(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
+  }
+}
+
+// scale = 1 / count for 'mean' (count = B*N for bce, B*(N-1) for bpr, B for sampled softmax), 1 for 'sum'
+extern "C" int sbr_rec_loss_fwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                                double* loss_out, void* stream) {
+  SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_fwd: unknown loss kind %d", kind);
+  SBR_REQUIRE(logits && loss_out && (kind == LOSS_SSM || labels), "sbr_rec_loss_fwd: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_rec_loss_fwd: memset failed"); return SBR_ERR_HIP; }
+  if (B == 0) return SBR_OK;
+  rec_loss_kernel<false><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, nullptr);
+  SBR_CHECK_LAUNCH("sbr_rec_loss_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_rec_loss_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                                const void* grad_out, int grad_out_is_double, float* dlogits, void* stream) {
+  SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_bwd: unknown loss kind %d", kind);
+  SBR_REQUIRE(logits && grad_out && dlogits && (kind == LOSS_SSM || labels), "sbr_rec_loss_bwd: null operand");
+  if (B == 0) return SBR_OK;
+  rec_loss_kernel<true><<<sbr_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(kind, logits, labels, B, N, scale, shift, nullptr,
+                                                                           grad_out, grad_out_is_double, dlogits);
+  SBR_CHECK_LAUNCH("sbr_rec_loss_bwd");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// InfoNCE (regularization_losses.py:14-43): groups g of N rows; logits L = A_g B_g^T / tau; symmetric cross entropy
+// against the diagonal. One workgroup per group; L lives in LDS ([N][N+1] floats).
+// A / B rows are addressed as base + (g*N + i) * ld, so the two modality slices e[..., 0, :] / e[..., 1, :] of the
+// [S, 2, D] embedding tensor are read in place (ld = 2*D).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void infonce_kernel(const float* __restrict__ A, const float* __restrict__ Bm, long ld, int N, int D,
+                               float inv_tau, double scale, double* __restrict__ loss_out, const float* __restrict__ gout,
+                               float* __restrict__ dA, float* __restrict__ dB, long ldg) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int LN = N + 1;
+  float* L = sm;                 // [N][N+1]
+  float* lse_r = sm + N * LN;    // [N]
+  float* lse_c = lse_r + N;      // [N]
+  const long g = blockIdx.x;
+  const float* a = A + g * N * ld;
+  const float* b = Bm + g * N * ld;
+  for (int p = threadIdx.x; p < N * N; p += blockDim.x) {
+    const int i = p / N, j = p - i * N;
+    float acc = 0.f;
+    for (int c = 0; c < D; ++c) acc += a[i * ld + c] * b[j * ld + c];
+    L[i * LN + j] = acc * inv_tau;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) {
+    const bool col = i >= N;
+    const int r = col ? i - N : i;
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) mx = fmaxf(mx, col ? L[j * LN + r] : L[r * LN + j]);
+    float se = 0.f;
+    for (int j = 0; j < N; ++j) se += expf((col ? L[j * LN + r] : L[r * LN + j]) - mx);
+    (col ? lse_c : lse_r)[r] = mx + logf(se);
+  }
+  __syncthreads();
+  if (!BWD) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) acc += (double)(lse_r[i] - L[i * LN + i]) + (double)(lse_c[i] - L[i * LN + i]);
+    __shared__ double red[4];
+    const double t = block_sum_d(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
+  } else {
+    const float up = gout[0] * (float)scale * inv_tau;
+    // G[i][j] = up * (softmax_row + softmax_col - 2*delta)
+    for (int p = threadIdx.x; p < N * N; p += blockDim.x) {
+      const int i = p / N, j = p - i * N;
+      const float l = L[i * LN + j];
+      L[i * LN + j] = up * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.f : 0.f));
+    }
+    __syncthreads();
+    float* da = dA + g * N * ldg;
+    float* db = dB + g * N * ldg;
+    for (int p = threadIdx.x; p < N * D; p += blockDim.x) {
+      const int i = p / D, c = p - i * D;
+      float sa = 0.f, sb = 0.f;
+      for (int j = 0; j < N; ++j) {
+        sa += L[i * LN + j] * b[j * ld + c];      // dA[i] = sum_j G[i][j] B[j]
+        sb += L[j * LN + i] * a[j * ld + c];      // dB[i] = sum_j G[j][i] A[j]
+      }
+      da[i * ldg + c] = sa;
+      db[i * ldg + c] = sb;
+    }
+  }
+}
+
+#define INFONCE_MAX_N 176
+
+static int infonce_lds(int N) { return (N * (N + 1) + 2 * N) * (int)sizeof(float); }
+
+extern "C" int sbr_infonce_max_n(void) { return INFONCE_MAX_N; }
+
+// scale = 1/(G*N) for 'mean', 1 for 'sum'
+extern "C" int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                               double* loss_out, void* stream) {
+  SBR_REQUIRE(A && B && loss_out, "sbr_infonce_fwd: null operand");
+  SBR_REQUIRE(N >= 1 && N <= INFONCE_MAX_N, "sbr_infonce_fwd: N=%d outside [1, %d]", N, INFONCE_MAX_N);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_infonce_fwd: memset failed"); return SBR_ERR_HIP; }
+  if (G == 0) return SBR_OK;
+  const int lds = infonce_lds(N);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)infonce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  infonce_kernel<false><<<(unsigned)G, 256, lds, s>>>(A, B, ld, N, D, 1.f / tau, scale, loss_out, nullptr, nullptr, nullptr, 0);
+  SBR_CHECK_LAUNCH("sbr_infonce_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                               const float* grad_out, float* dA, float* dB, long ldg, void* stream) {
+  SBR_REQUIRE(A && B && grad_out && dA && dB, "sbr_infonce_bwd: null operand");
+  SBR_REQUIRE(N >= 1 && N <= INFONCE_MAX_N, "sbr_infonce_bwd: N=%d outside [1, %d]", N, INFONCE_MAX_N);
+  if (G == 0) return SBR_OK;
+  const int lds = infonce_lds(N);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)infonce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  infonce_kernel<true><<<(unsigned)G, 256, lds, (hipStream_t)stream>>>(A, B, ld, N, D, 1.f / tau, scale, nullptr, grad_out, dA, dB, ldg);
+  SBR_CHECK_LAUNCH("sbr_infonce_bwd");
+  return SBR_OK;
+}

@@ -1,0 +1,496 @@
+// Row-wise (HBM-bound) kernels of the SingleBranchNet hot path: index resolution, embedding lookups / bags,
+// the CSR "interactions" projector, activation-gradient gathers, column sums, L2 normalisation, dropout,
+// modality aggregation and the per-slot user x item dot product.
+// All of them move rows of C..D floats; lanes run along the feature dimension so that every wave instruction
+// touches one contiguous 256-byte (or wider) segment of a row.
+#include "common.h"
+
+#define SBR_MAX_SEG 16
+
+struct SegTable {
+  int n_seg;
+  int offs[SBR_MAX_SEG + 1];
+  const int* maps[SBR_MAX_SEG];
+};
+
+// rows[j] = map_seg(j)[ idx[slots[j] / k] ]  — Feature.__getitem__'s id -> row map (data/Feature.py:146) applied to the
+// flattened, k-times repeated index tensor of SingleBranchNetEntity._get_modality_embeddings (sgd_alg.py:1944-1946).
+__global__ void resolve_rows_kernel(const long* __restrict__ idx, int k, const int* __restrict__ slots, int n,
+                                    SegTable st, int* __restrict__ rows, int* __restrict__ err) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int seg = 0;
+  while (seg + 1 < st.n_seg && j >= st.offs[seg + 1]) ++seg;
+  const long id = idx[slots[j] / k];
+  int r = (int)id;
+  if (st.maps[seg]) r = st.maps[seg][id];
+  if (r < 0) atomicExch(err, 1);       // id not present in this feature's split
+  rows[j] = r;
+}
+
+extern "C" int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg, const int* seg_offsets,
+                                const int* const* rowmaps, int* rows_out, int* err_flag, void* stream) {
+  SBR_REQUIRE(n_seg >= 1 && n_seg <= SBR_MAX_SEG, "sbr_resolve_rows: n_seg %d out of range", n_seg);
+  SBR_REQUIRE(k >= 1, "sbr_resolve_rows: k must be >= 1");
+  if (n == 0) return SBR_OK;
+  SegTable st;
+  st.n_seg = n_seg;
+  for (int i = 0; i <= n_seg; ++i) st.offs[i] = seg_offsets[i];
+  for (int i = 0; i < n_seg; ++i) st.maps[i] = rowmaps[i];
+  resolve_rows_kernel<<<sbr_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(idx, k, slots, n, st, rows_out, err_flag);
+  SBR_CHECK_LAUNCH("sbr_resolve_rows");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// nn.Embedding lookup (sgd_alg.py:1331,1386): out[oi(j), :] = W[rows[j], :]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ W, long ldw, const int* __restrict__ rows,
+                                   float* __restrict__ out, long ldo, const int* __restrict__ out_idx, long n, int D) {
+  const long total = n * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long j = e / D;
+    const int c = (int)(e - j * D);
+    const long o = out_idx ? out_idx[j] : j;
+    out[o * ldo + c] = W[(long)rows[j] * ldw + c];
+  }
+}
+
+extern "C" int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx,
+                               long n, int D, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(W && rows && out, "sbr_gather_rows: null operand");
+  int blocks = sbr_cdiv(n * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(W, ldw, rows, out, ldo, out_idx, n, D);
+  SBR_CHECK_LAUNCH("sbr_gather_rows");
+  return SBR_OK;
+}
+
+// backward of the lookup: dW[rows[j], :] += scale * dOut[ii(j), :]   (float atomics into a zero-initialised dense gradient;
+// the reference's dense nn.Embedding gradient, consumed by a dense optimizer — trainer.py:62-68)
+__global__ void scatter_add_rows_kernel(const float* __restrict__ dOut, long ldo, const int* __restrict__ in_idx,
+                                        const int* __restrict__ rows, float* __restrict__ dW, long ldw, long n, int D) {
+  const long total = n * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long j = e / D;
+    const int c = (int)(e - j * D);
+    const long i = in_idx ? in_idx[j] : j;
+    atomicAdd(&dW[(long)rows[j] * ldw + c], dOut[i * ldo + c]);
+  }
+}
+
+extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW,
+                                    long ldw, long n, int D, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(dOut && rows && dW, "sbr_scatter_add_rows: null operand");
+  int blocks = sbr_cdiv(n * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  scatter_add_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n, D);
+  SBR_CHECK_LAUNCH("sbr_scatter_add_rows");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// nn.EmbeddingBag(mode='mean', padding_idx=pad) over padded tag lists (sgd_alg.py:1336-1337; Feature.py:254-255)
+// one wave per output row; lanes run along D
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void bag_mean_fwd_kernel(const float* __restrict__ W, long ldw, const int* __restrict__ tags, int T, int pad,
+                                    const int* __restrict__ rows, float* __restrict__ out, long ldo,
+                                    const int* __restrict__ out_idx, long n, int D) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int* tg = tags + (long)rows[j] * T;
+  const long o = (out_idx ? (long)out_idx[j] : j) * ldo;
+  int cnt = 0;
+  for (int q = 0; q < T; ++q) cnt += (tg[q] != pad);
+  const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+  for (int c = lane; c < D; c += 64) {
+    float acc = 0.f;
+    for (int q = 0; q < T; ++q) {
+      const int tq = tg[q];
+      if (tq != pad) acc += W[(long)tq * ldw + c];
+    }
+    out[o + c] = acc * inv;
+  }
+}
+
+__global__ void bag_mean_bwd_kernel(const float* __restrict__ dOut, long ldo, const int* __restrict__ in_idx,
+                                    const int* __restrict__ tags, int T, int pad, const int* __restrict__ rows,
+                                    float* __restrict__ dW, long ldw, long n, int D) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int* tg = tags + (long)rows[j] * T;
+  const long i = (in_idx ? (long)in_idx[j] : j) * ldo;
+  int cnt = 0;
+  for (int q = 0; q < T; ++q) cnt += (tg[q] != pad);
+  if (cnt == 0) return;
+  const float inv = 1.f / (float)cnt;
+  for (int c = lane; c < D; c += 64) {
+    const float g = dOut[i + c] * inv;
+    for (int q = 0; q < T; ++q) {
+      const int tq = tg[q];
+      if (tq != pad) atomicAdd(&dW[(long)tq * ldw + c], g);
+    }
+  }
+}
+
+extern "C" int sbr_bag_mean_fwd(const float* W, long ldw, const int* tags, int T, int pad, const int* rows, float* out,
+                                long ldo, const int* out_idx, long n, int D, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(W && tags && rows && out, "sbr_bag_mean_fwd: null operand");
+  bag_mean_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(W, ldw, tags, T, pad, rows, out, ldo, out_idx, n, D);
+  SBR_CHECK_LAUNCH("sbr_bag_mean_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_bag_mean_bwd(const float* dOut, long ldo, const int* in_idx, const int* tags, int T, int pad,
+                                const int* rows, float* dW, long ldw, long n, int D, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(dOut && tags && rows && dW, "sbr_bag_mean_bwd: null operand");
+  bag_mean_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, tags, T, pad, rows, dW, ldw, n, D);
+  SBR_CHECK_LAUNCH("sbr_bag_mean_bwd");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Linear over a CSR "interactions" row without densifying it (reference: Feature.py:149-150 toarray() +
+// Linear(n_cols -> C), sgd_alg.py:1380, polylinear.py:51):   out[oi(j), :] = act(bias + sum_{q in row} val_q * Wt[col_q, :])
+// Wt is the projector weight stored column-major ([n_cols, C] rows of C floats), so every nnz reads one contiguous row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void csr_project_fwd_kernel(const long* __restrict__ indptr, const int* __restrict__ indices,
+                                       const float* __restrict__ vals, const float* __restrict__ Wt, long ldw,
+                                       const float* __restrict__ bias, const int* __restrict__ rows,
+                                       float* __restrict__ out, long ldo, const int* __restrict__ out_idx, long n,
+                                       int C, int act) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const long r = rows[j];
+  const long beg = indptr[r], end = indptr[r + 1];
+  const long o = (out_idx ? (long)out_idx[j] : j) * ldo;
+  for (int c = lane; c < C; c += 64) {
+    float acc = 0.f;
+    for (long q = beg; q < end; ++q) {
+      const float w = Wt[(long)indices[q] * ldw + c];
+      acc += vals ? vals[q] * w : w;
+    }
+    if (bias) acc += bias[c];
+    out[o + c] = sbr_act(acc, act);
+  }
+}
+
+// dWt[col_q, :] += val_q * dZ[j, :]
+__global__ void csr_project_bwd_kernel(const long* __restrict__ indptr, const int* __restrict__ indices,
+                                       const float* __restrict__ vals, const float* __restrict__ dZ, long ldz,
+                                       const int* __restrict__ rows, float* __restrict__ dWt, long ldw, long n, int C) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const long r = rows[j];
+  const long beg = indptr[r], end = indptr[r + 1];
+  for (int c = lane; c < C; c += 64) {
+    const float g = dZ[j * ldz + c];
+    for (long q = beg; q < end; ++q) atomicAdd(&dWt[(long)indices[q] * ldw + c], vals ? vals[q] * g : g);
+  }
+}
+
+extern "C" int sbr_csr_project_fwd(const long* indptr, const int* indices, const float* vals, const float* Wt, long ldw,
+                                   const float* bias, const int* rows, float* out, long ldo, const int* out_idx, long n,
+                                   int C, int act, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(indptr && indices && Wt && rows && out, "sbr_csr_project_fwd: null operand");
+  csr_project_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out,
+                                                                          ldo, out_idx, n, C, act);
+  SBR_CHECK_LAUNCH("sbr_csr_project_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_csr_project_bwd(const long* indptr, const int* indices, const float* vals, const float* dZ, long ldz,
+                                   const int* rows, float* dWt, long ldw, long n, int C, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(indptr && indices && dZ && rows && dWt, "sbr_csr_project_bwd: null operand");
+  csr_project_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, n, C);
+  SBR_CHECK_LAUNCH("sbr_csr_project_bwd");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dZ[j, :] = dY[ii(j), :] * act'(Y[ii(j), :])       (gather fused with the activation derivative)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void act_grad_gather_kernel(const float* __restrict__ dY, const float* __restrict__ Y, long ld,
+                                       const int* __restrict__ in_idx, float* __restrict__ dZ, long ldz, long n, int C,
+                                       int act) {
+  const long total = n * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long j = e / C;
+    const int c = (int)(e - j * C);
+    const long i = (in_idx ? (long)in_idx[j] : j) * ld + c;
+    dZ[j * ldz + c] = dY[i] * sbr_act_grad_from_out(Y[i], act);
+  }
+}
+
+extern "C" int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz,
+                                   long n, int C, int act, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(dY && Y && dZ, "sbr_act_grad_gather: null operand");
+  int blocks = sbr_cdiv(n * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  act_grad_gather_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dY, Y, ld, in_idx, dZ, ldz, n, C, act);
+  SBR_CHECK_LAUNCH("sbr_act_grad_gather");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums (bias gradients): out[c] = sum_j X[j, c]; double accumulation, one atomic per block and column
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float* __restrict__ X, long ld, long n, int C, double* __restrict__ acc) {
+  // block = 256 threads as 4 row-groups x 64 columns
+  const int cg = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double s = 0.0;
+  if (cg < C)
+    for (long j = blockIdx.x * 4L + rg; j < n; j += gridDim.x * 4L) s += (double)X[j * ld + cg];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (rg == 0 && cg < C) atomicAdd(&acc[cg], sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+}
+
+__global__ void d2f_kernel(const double* __restrict__ a, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)a[i];
+}
+
+// workspace: C doubles, zeroed by this call
+extern "C" int sbr_colsum(const float* X, long ld, long n, int C, float* out, double* workspace, void* stream) {
+  SBR_REQUIRE(out && workspace, "sbr_colsum: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, sizeof(double) * C, s) != hipSuccess) { sbr_set_error("sbr_colsum: memset failed"); return SBR_ERR_HIP; }
+  if (n > 0) {
+    int bx = sbr_cdiv(n, 64);
+    if (bx > 512) bx = 512;
+    colsum_kernel<<<dim3(bx, sbr_cdiv(C, 64)), 256, 0, s>>>(X, ld, n, C, workspace);
+    SBR_CHECK_LAUNCH("sbr_colsum");
+  }
+  d2f_kernel<<<sbr_cdiv(C, 256), 256, 0, s>>>(workspace, out, C);
+  SBR_CHECK_LAUNCH("sbr_colsum/d2f");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F.normalize(x, p=2, dim=-1, eps) (sgd_alg.py:1873-1874): y = x / max(||x||, eps). One wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ inv_norm,
+                                  long n, int C, float eps) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = X[j * C + c]; ss += v * v; }
+  ss = sbr_wave_sum(ss);
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  for (int c = lane; c < C; c += 64) Y[j * C + c] = X[j * C + c] * inv;
+  if (lane == 0) inv_norm[j] = inv;
+}
+
+// dx = inv * (dy - y * (y . dy))  when ||x|| > eps, else dy / eps
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                  const float* __restrict__ inv_norm, float* __restrict__ dX, long n, int C, float eps) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float inv = inv_norm[j];
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += Y[j * C + c] * dY[j * C + c];
+  dot = sbr_wave_sum(dot);
+  const bool clamped = inv >= 1.f / eps;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dY[j * C + c];
+    dX[j * C + c] = clamped ? g * inv : inv * (g - Y[j * C + c] * dot);
+  }
+}
+
+extern "C" int sbr_l2norm_fwd(const float* X, float* Y, float* inv_norm, long n, int C, float eps, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y && inv_norm, "sbr_l2norm_fwd: null operand");
+  l2norm_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(X, Y, inv_norm, n, C, eps);
+  SBR_CHECK_LAUNCH("sbr_l2norm_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_l2norm_bwd(const float* dY, const float* Y, const float* inv_norm, float* dX, long n, int C, float eps,
+                              void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(dY && Y && inv_norm && dX, "sbr_l2norm_bwd: null operand");
+  l2norm_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(dY, Y, inv_norm, dX, n, C, eps);
+  SBR_CHECK_LAUNCH("sbr_l2norm_bwd");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// nn.Dropout(p) (sgd_alg.py:1815, polylinear.py:48) with a counter-based generator: element e is kept iff
+// hash(seed, e) >= p * 2^32. The backward pass recomputes the mask from (seed, e); nothing is stored.
+// (The reference draws its mask from torch's CPU generator; a GPU mask cannot reproduce that stream — parity tests
+// run with dropout disabled, SURVEY.md §7 "Hard parts".)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int sbr_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (unsigned int)(z >> 32);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ X, float* __restrict__ Y, long total, float p,
+                               unsigned long long seed) {
+  const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
+  const float scale = 1.f / (1.f - p);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    Y[e] = sbr_mix(seed * 0x100000001B3ULL + (unsigned long long)e) >= thr ? X[e] * scale : 0.f;
+}
+
+// forward and backward are the same map (y = x * m / (1-p)); pass dY as X for the backward
+extern "C" int sbr_dropout(const float* X, float* Y, long total, float p, unsigned long long seed, void* stream) {
+  if (total == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y, "sbr_dropout: null operand");
+  SBR_REQUIRE(p >= 0.f && p < 1.f, "sbr_dropout: p must be in [0, 1)");
+  int blocks = sbr_cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  dropout_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, Y, total, p, seed);
+  SBR_CHECK_LAUNCH("sbr_dropout");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// aggregation over the k sampled modalities (sgd_alg.py:27-31, 1861): E [S, k, D] -> out [S, D]; mode 0 mean, 1 max
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void aggregate_fwd_kernel(const float* __restrict__ E, float* __restrict__ out, unsigned char* __restrict__ arg,
+                                     long S, int k, int D, int mode) {
+  const long total = S * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long s = e / D;
+    const int c = (int)(e - s * D);
+    const float* p = E + s * k * D + c;
+    if (mode == 0) {
+      float acc = 0.f;
+      for (int q = 0; q < k; ++q) acc += p[(long)q * D];
+      out[e] = acc / (float)k;
+    } else {
+      float best = p[0];
+      int bi = 0;
+      for (int q = 1; q < k; ++q) {
+        const float v = p[(long)q * D];
+        if (v > best) { best = v; bi = q; }
+      }
+      out[e] = best;
+      arg[e] = (unsigned char)bi;
+    }
+  }
+}
+
+__global__ void aggregate_bwd_kernel(const float* __restrict__ dOut, const unsigned char* __restrict__ arg,
+                                     float* __restrict__ dE, long S, int k, int D, int mode) {
+  const long total = S * k * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long s = e / ((long)k * D);
+    const int rem = (int)(e - s * k * D);
+    const int q = rem / D, c = rem - q * D;
+    const float g = dOut[s * D + c];
+    dE[e] = mode == 0 ? g / (float)k : (arg[s * D + c] == q ? g : 0.f);
+  }
+}
+
+extern "C" int sbr_aggregate_fwd(const float* E, float* out, unsigned char* argmax, long S, int k, int D, int mode,
+                                 void* stream) {
+  if (S == 0) return SBR_OK;
+  SBR_REQUIRE(E && out && (mode == 0 || argmax), "sbr_aggregate_fwd: null operand");
+  SBR_REQUIRE(k >= 1 && k <= 255, "sbr_aggregate_fwd: k out of range");
+  int blocks = sbr_cdiv(S * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  aggregate_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(E, out, argmax, S, k, D, mode);
+  SBR_CHECK_LAUNCH("sbr_aggregate_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_aggregate_bwd(const float* dOut, const unsigned char* argmax, float* dE, long S, int k, int D, int mode,
+                                 void* stream) {
+  if (S == 0) return SBR_OK;
+  SBR_REQUIRE(dOut && dE && (mode == 0 || argmax), "sbr_aggregate_bwd: null operand");
+  int blocks = sbr_cdiv(S * k * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  aggregate_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, argmax, dE, S, k, D, mode);
+  SBR_CHECK_LAUNCH("sbr_aggregate_bwd");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the training scorer einsum('be,bce->bc') (sgd_alg.py:2114): logits[b, n] = u[b, :] . i[b, n, :]
+// one wave per (b, n) slot, wavefront shuffle reduction
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void score_dot_fwd_kernel(const float* __restrict__ U, const float* __restrict__ I, float* __restrict__ out,
+                                     long B, int N, int D) {
+  const long s = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= B * N) return;
+  const int lane = threadIdx.x & 63;
+  const long b = s / N;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) acc += U[b * D + c] * I[s * D + c];
+  acc = sbr_wave_sum(acc);
+  if (lane == 0) out[s] = acc;
+}
+
+// dU[b, :] = sum_n g[b, n] * I[b, n, :] ;  dI[b, n, :] = g[b, n] * U[b, :]      one block per b
+__global__ void score_dot_bwd_kernel(const float* __restrict__ G, const float* __restrict__ U,
+                                     const float* __restrict__ I, float* __restrict__ dU, float* __restrict__ dI, int N,
+                                     int D) {
+  const long b = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float u = U[b * D + c];
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float g = G[b * N + n];
+      acc += g * I[(b * N + n) * D + c];
+      if (dI) dI[(b * N + n) * D + c] = g * u;
+    }
+    if (dU) dU[b * D + c] = acc;
+  }
+}
+
+extern "C" int sbr_score_dot_fwd(const float* U, const float* I, float* out, long B, int N, int D, void* stream) {
+  if (B * N == 0) return SBR_OK;
+  SBR_REQUIRE(U && I && out, "sbr_score_dot_fwd: null operand");
+  score_dot_fwd_kernel<<<sbr_cdiv(B * N, 4), 256, 0, (hipStream_t)stream>>>(U, I, out, B, N, D);
+  SBR_CHECK_LAUNCH("sbr_score_dot_fwd");
+  return SBR_OK;
+}
+
+extern "C" int sbr_score_dot_bwd(const float* G, const float* U, const float* I, float* dU, float* dI, long B, int N,
+                                 int D, void* stream) {
+  if (B == 0) return SBR_OK;
+  SBR_REQUIRE(G && U && I, "sbr_score_dot_bwd: null operand");
+  const int threads = D >= 256 ? 256 : (D > 64 ? 128 : 64);
+  score_dot_bwd_kernel<<<(unsigned)B, threads, 0, (hipStream_t)stream>>>(G, U, I, dU, dI, N, D);
+  SBR_CHECK_LAUNCH("sbr_score_dot_bwd");
+  return SBR_OK;
+}
+
+// SGDBaseline (sgd_alg.py:110-119): out[b, n] = user_bias[u[b]] + item_bias[i[b, n]] + global_bias
+__global__ void bias_score_kernel(const float* __restrict__ ub, const float* __restrict__ ib, const float* __restrict__ gb,
+                                  const long* __restrict__ u, const long* __restrict__ i, float* __restrict__ out, long B,
+                                  int N) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= B * N) return;
+  out[e] = ub[u[e / N]] + ib[i[e]] + gb[0];
+}
+
+extern "C" int sbr_bias_score_fwd(const float* user_bias, const float* item_bias, const float* global_bias, const long* u,
+                                  const long* i, float* out, long B, int N, void* stream) {
+  if (B * N == 0) return SBR_OK;
+  SBR_REQUIRE(user_bias && item_bias && global_bias && u && i && out, "sbr_bias_score_fwd: null operand");
+  bias_score_kernel<<<sbr_cdiv(B * N, 256), 256, 0, (hipStream_t)stream>>>(user_bias, item_bias, global_bias, u, i, out, B, N);
+  SBR_CHECK_LAUNCH("sbr_bias_score_fwd");
+  return SBR_OK;
+}

@@ -1,0 +1,284 @@
+// Fused full-catalogue scorer for evaluation (eval/eval.py:205-222 without ever writing the [users, items] score matrix):
+//   scores = U[Bu, D] x I[I_s, D]^T on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate),
+//   out[b, excl(u_b)] = -inf (eval.py:219-220) applied to the few values that matter,
+//   running exact top-k per user kept on chip; output sorted by (score desc, item index asc).
+//
+// Geometry: one workgroup = 8 wavefronts = 256 users; wave w owns users [32w, 32w+32) of the block for the whole kernel and
+// keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is streamed once per workgroup
+// through a double-buffered, XOR-swizzled LDS tile of 64 items; every wave multiplies its 32 users by the 64 items
+// (2 x D/16 MFMAs per tile). Each accumulator value is compared with its row's current k-th best score held in a register;
+// only the rare survivors are checked against the user's exclusion list (binary search in the CSR row) and appended to the
+// row's candidate buffer in LDS. A full buffer is compacted by its owning wave (rank by counting), which raises the row's
+// threshold. Rows are owned by exactly one wave, so no cross-wave synchronisation is needed for the top-k state.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ST_ROWS 256       // users per workgroup
+#define ST_TILE 64        // items per LDS tile
+#define ST_THREADS 512
+
+__device__ __forceinline__ unsigned int st_f2key(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float st_key2f(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+struct TopkState {
+  unsigned long long* buf;   // [ST_ROWS][cap] composite keys (score key << 32 | ~item)
+  int* cnt;                  // [ST_ROWS]
+  long* ebeg;                // [ST_ROWS] exclusion CSR row bounds of each user of the block (ebeg > eend: row is padding)
+  long* eend;                // [ST_ROWS]
+  int cap, k;
+};
+
+// all 64 lanes of the owning wave: keep the k best of row r's buffer, sorted; returns the new threshold
+__device__ __forceinline__ float st_compact(const TopkState& st, int r, int lane) {
+  unsigned long long* b = st.buf + r * st.cap;
+  int n = st.cnt[r];
+  n = n < st.cap ? n : st.cap;
+  const unsigned long long mine = lane < n ? b[lane] : 0ull;
+  int rank = 0;
+  for (int j = 0; j < n; ++j) rank += (b[j] > mine);
+  if (lane < n && rank < st.k) b[rank] = mine;
+  const int kept = n < st.k ? n : st.k;
+  if (lane == 0) st.cnt[r] = kept;
+  const unsigned long long who = __ballot(lane < n && rank == st.k - 1);
+  float thr = -INFINITY;
+  if (who) thr = st_key2f((unsigned int)(__shfl(mine, __ffsll((long long)who) - 1, 64) >> 32));
+  return thr;
+}
+
+// slow path of one accumulator register step. Returns the (possibly raised) threshold of this lane's row.
+__device__ __noinline__ float st_insert(TopkState st, float v, bool cand, int row, int gitem, float thr,
+                                        const int* __restrict__ excl, int lane) {
+  if (cand) {      // exclusion check: binary search in the user's sorted exclusion row
+    const long ebeg = st.ebeg[row], eend = st.eend[row];
+    if (ebeg > eend) cand = false;      // padding row of the last block
+    long lo = ebeg, hi = eend;
+    while (lo < hi) {
+      const long mid = (lo + hi) >> 1;
+      if (excl[mid] < gitem) lo = mid + 1; else hi = mid;
+    }
+    if (lo < eend && excl[lo] == gitem) cand = false;
+  }
+  const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)gitem);
+  bool pending = cand;
+  while (__ballot(pending)) {
+    if (pending) {
+      const int pos = atomicAdd(&st.cnt[row], 1);
+      if (pos < st.cap) { st.buf[row * st.cap + pos] = key; pending = false; }
+    }
+    unsigned long long ov = __ballot(pending);
+    while (ov) {
+      const int src = __ffsll((long long)ov) - 1;
+      const int r = __shfl(row, src, 64);
+      const float nt = st_compact(st, r, lane);
+      if (row == r) {
+        thr = nt;
+        if (pending && !(v > thr)) pending = false;
+      }
+      ov &= ~__ballot(row == r);
+    }
+  }
+  return thr;
+}
+
+template <int KS>   // KS = D / 16
+__global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
+    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
+    const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
+    float* __restrict__ out_val, int* __restrict__ out_idx) {
+  constexpr int D = KS * 16;
+  constexpr int ROWB = D * 2;              // bytes per item row
+  constexpr int TILEB = ST_TILE * ROWB;    // bytes per LDS tile
+  constexpr int SWZ = (D / 8 >= 16) ? 15 : (D / 8 - 1);   // XOR swizzle mask over the 16-byte chunks of a row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tile0 = smem;
+  unsigned char* tile1 = smem + TILEB;
+  TopkState st;
+  st.buf = reinterpret_cast<unsigned long long*>(smem + 2 * TILEB);
+  st.ebeg = reinterpret_cast<long*>(smem + 2 * TILEB + (size_t)ST_ROWS * cap * 8);
+  st.eend = st.ebeg + ST_ROWS;
+  st.cnt = reinterpret_cast<int*>(st.eend + ST_ROWS);
+  st.cap = cap;
+  st.k = k;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const long row0 = (long)blockIdx.x * ST_ROWS;
+
+  if (t < ST_ROWS) {
+    st.cnt[t] = 0;
+    const long ur = row0 + t;
+    long eb = 1, ee = 0;                 // padding row
+    if (ur < Bu) {
+      eb = ee = 0;
+      if (excl_indptr) {
+        const long u = u_idx ? u_idx[ur] : ur;
+        eb = excl_indptr[u];
+        ee = excl_indptr[u + 1];
+      }
+    }
+    st.ebeg[t] = eb;
+    st.eend[t] = ee;
+  }
+
+  // A fragments: user row (32*wave + l31), k = 16*s + 8*half + j
+  f16x8 afrag[KS];
+  {
+    long ur = row0 + wave * 32 + l31;
+    if (ur >= Bu) ur = Bu - 1;
+    const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) afrag[s] = src[2 * s + half];
+  }
+  // the rows whose accumulators this lane sees: local row (reg&3) + 8*(reg>>2) + 4*half of the wave's 32
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+
+  // item tile staging: ST_TILE rows x (D/8) 16-byte chunks; chunk c of row i is stored at chunk position c ^ (i & SWZ)
+  constexpr int CHUNKS = ST_TILE * (D / 8);
+  constexpr int PER_T = (CHUNKS + ST_THREADS - 1) / ST_THREADS;
+  uint4 stage[PER_T];
+  auto g_load = [&](int j0) {
+#pragma unroll
+    for (int p = 0; p < PER_T; ++p) {
+      const int ch = t + p * ST_THREADS;
+      const int i = ch / (D / 8), c = ch % (D / 8);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (ch < CHUNKS && j0 + i < I) v = *reinterpret_cast<const uint4*>(It + (long)(j0 + i) * D + c * 8);
+      stage[p] = v;
+    }
+  };
+  auto s_store = [&](unsigned char* tile) {
+#pragma unroll
+    for (int p = 0; p < PER_T; ++p) {
+      const int ch = t + p * ST_THREADS;
+      if (ch < CHUNKS) {
+        const int i = ch / (D / 8), c = ch % (D / 8);
+        *reinterpret_cast<uint4*>(tile + i * ROWB + ((c ^ (i & SWZ)) << 4)) = stage[p];
+      }
+    }
+  };
+
+  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
+  g_load(0);
+  s_store(tile0);
+  __syncthreads();
+  for (int tl = 0; tl < n_tiles; ++tl) {
+    unsigned char* cur = (tl & 1) ? tile1 : tile0;
+    unsigned char* nxt = (tl & 1) ? tile0 : tile1;
+    if (tl + 1 < n_tiles) g_load((tl + 1) * ST_TILE);
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const int i = nj * 32 + l31;                       // item row within the tile
+        const int c = 2 * s + half;                        // 16-byte chunk: k = 16 s + 8 half .. +7
+        const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));
+        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], b, acc[nj], 0, 0, 0);
+      }
+    }
+    // epilogue: threshold filter
+    const int j0 = tl * ST_TILE;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int item = j0 + nj * 32 + l31;
+      const bool in_range = item < I;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[nj][r];
+        const bool cand = in_range && (v > thr[r]);
+        if (__ballot(cand)) {
+          const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          thr[r] = st_insert(st, v, cand, lrow, item_offset + item, thr[r], excl_indices, lane);
+        }
+      }
+    }
+    if (tl + 1 < n_tiles) s_store(nxt);
+    __syncthreads();
+  }
+
+  // final compaction + output: wave-owned rows
+  for (int q = 0; q < 32; ++q) {
+    const int lrow = wave * 32 + q;
+    const long ur = row0 + lrow;
+    if (ur >= Bu) break;
+    st_compact(st, lrow, lane);
+    const int n = st.cnt[lrow];
+    if (lane < k) {
+      float val = -INFINITY;
+      int idx = -1;
+      if (lane < n) {
+        const unsigned long long c = st.buf[lrow * cap + lane];
+        val = st_key2f((unsigned int)(c >> 32));
+        idx = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
+      }
+      out_val[ur * k + lane] = val;
+      out_idx[ur * k + lane] = idx;
+    }
+  }
+}
+
+static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64) c = 64; return c; }
+
+extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
+
+template <int KS>
+static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+                     int item_offset, int k, float* out_val, int* out_idx, hipStream_t s) {
+  const int cap = st_cap(k);
+  const size_t lds = 2 * (size_t)ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_ROWS * (8 + 8 + 4);
+  SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
+  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
+    return SBR_ERR_HIP;
+  }
+  score_topk_f16_kernel<KS><<<sbr_cdiv(Bu, ST_ROWS), ST_THREADS, lds, s>>>(
+      (const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k, cap, out_val, out_idx);
+  SBR_CHECK_LAUNCH("sbr_score_topk_f16");
+  return SBR_OK;
+}
+
+extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
+                                  const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val,
+                                  int* out_idx, void* workspace, long workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
+  SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(U_f16 && I_f16 && out_val && out_idx, "sbr_score_topk_f16: null operand");
+  SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 64: return st_launch<4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 128: return st_launch<8>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 256: return st_launch<16>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    default:
+      sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
+      return SBR_ERR_ARG;
+  }
+}
+
+__global__ void cast_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Y, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) Y[e] = (_Float16)X[e];
+}
+
+extern "C" int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y_f16, "sbr_cast_f32_to_f16: null operand");
+  int blocks = sbr_cdiv(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  cast_f16_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, (_Float16*)Y_f16, n);
+  SBR_CHECK_LAUNCH("sbr_cast_f32_to_f16");
+  return SBR_OK;
+}

@@ -1,0 +1,193 @@
+// Full-catalogue evaluation helpers (eval/eval.py:205-222): exclusion mask, per-user top-k and ranking metrics.
+//   sbr_mask_scores   out[b, excl(u_b)] = -inf          (eval.py:219-220, CSR rows instead of a dense bool matrix)
+//   sbr_topk_rows     exact top-k of every score row, sorted by (score desc, index asc)  (torch.topk, eval.py:320)
+//   sbr_rank_metrics  NDCG / recall / precision @k from the top-k indices and the CSR labels (eval/metrics.py:4-105)
+// Integer / ordering work: results are exact (no tolerance); the only freedom is the order of exactly tied scores,
+// which torch.topk leaves unspecified and which is fixed here to "lower index first".
+#include "common.h"
+
+__global__ void mask_scores_kernel(float* __restrict__ S, long ld, const long* __restrict__ u_idx,
+                                   const long* __restrict__ indptr, const int* __restrict__ indices, long Bu) {
+  const long b = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= Bu) return;
+  const long u = u_idx ? u_idx[b] : b;
+  for (long q = indptr[u] + (threadIdx.x & 63); q < indptr[u + 1]; q += 64) S[b * ld + indices[q]] = -INFINITY;
+}
+
+extern "C" int sbr_mask_scores(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices,
+                               long Bu, void* stream) {
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(scores && excl_indptr && excl_indices, "sbr_mask_scores: null operand");
+  mask_scores_kernel<<<sbr_cdiv(Bu, 4), 256, 0, (hipStream_t)stream>>>(scores, ld, u_idx, excl_indptr, excl_indices, Bu);
+  SBR_CHECK_LAUNCH("sbr_mask_scores");
+  return SBR_OK;
+}
+
+// order-preserving map float -> uint32 (larger float <=> larger key; -inf is the smallest non-NaN key)
+__device__ __forceinline__ unsigned int f2key(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+#define TOPK_MAX 256
+
+// one 256-thread workgroup per row: 4-pass 8-bit radix select of the k-th largest key, ordered collection, bitonic sort
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, long ld, int I, int k, int kpad,
+                                                        float* __restrict__ out_val, int* __restrict__ out_idx) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long cand[TOPK_MAX];
+  __shared__ unsigned int s_prefix, s_need, s_cnt, s_wave[4], s_taken;
+  const float* row = S + blockIdx.x * ld;
+  const int t = threadIdx.x;
+
+  if (t == 0) { s_prefix = 0; s_need = (unsigned)k; }
+  unsigned int prefix = 0, need = (unsigned)k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[t] = 0;
+    __syncthreads();
+    const unsigned int hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = t; i < I; i += 256) {
+      const unsigned int key = f2key(row[i]);
+      if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned int acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      s_prefix = prefix | ((unsigned)d << shift);
+      s_need = need - acc;              // how many keys with this digit (and the same higher digits) are still needed
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    __syncthreads();
+  }
+  // prefix is now the key of the k-th largest element; `need` of the elements equal to it belong to the top-k
+  const unsigned int T = prefix;
+  if (t == 0) { s_cnt = 0; s_taken = 0; }
+  for (int i = t; i < kpad; i += 256) cand[i] = 0ull;       // padding sorts last
+  __syncthreads();
+  for (int i = t; i < I; i += 256) {
+    const unsigned int key = f2key(row[i]);
+    if (key > T) {
+      const unsigned int pos = atomicAdd(&s_cnt, 1u);
+      cand[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+  }
+  __syncthreads();
+  const unsigned int base = s_cnt;       // == k - need
+  // ties at the threshold: the `need` lowest indices, found by an ordered sweep
+  const int lane = t & 63, w = t >> 6;
+  for (int i0 = 0; i0 < I; i0 += 256) {
+    const int i = i0 + t;
+    const bool eq = i < I && f2key(row[i]) == T;
+    const unsigned long long bal = __ballot(eq);
+    if (lane == 0) s_wave[w] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned int before = s_taken;
+    for (int q = 0; q < w; ++q) before += s_wave[q];
+    const unsigned int mine = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (eq && mine < need) cand[base + mine] = ((unsigned long long)T << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    __syncthreads();
+    if (t == 0) s_taken += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    if (s_taken >= need) break;
+  }
+  __syncthreads();
+  // bitonic sort, descending, on kpad (power of two <= 256) composite keys
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int i = t;
+      if (i < kpad) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = (i & size) == 0;
+          const unsigned long long a = cand[i], b = cand[j];
+          if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < k) {
+    const unsigned long long c = cand[t];
+    out_val[blockIdx.x * (long)k + t] = key2f((unsigned int)(c >> 32));
+    out_idx[blockIdx.x * (long)k + t] = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
+  }
+}
+
+extern "C" int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k, float* out_val, int* out_idx, void* stream) {
+  SBR_REQUIRE(k >= 1 && k <= TOPK_MAX, "sbr_topk_rows: k=%d outside [1, %d]", k, TOPK_MAX);
+  SBR_REQUIRE(k <= I, "sbr_topk_rows: k=%d larger than the row length %d", k, I);
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(scores && out_val && out_idx, "sbr_topk_rows: null operand");
+  int kpad = 2;
+  while (kpad < k) kpad <<= 1;
+  topk_rows_kernel<<<(unsigned)Bu, 256, 0, (hipStream_t)stream>>>(scores, ld, I, k, kpad, out_val, out_idx);
+  SBR_CHECK_LAUNCH("sbr_topk_rows");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ranking metrics with binary relevance (eval/metrics.py): for each user b and each cutoff ks[q]
+//   hits   = #{r < k : topk[b, r] in labels(u_b)}
+//   recall = hits / n_pos (0 when n_pos == 0), precision = hits / k,
+//   ndcg   = min(1, sum_{r<k, hit} 1/log2(r+2) / sum_{r<min(k,n_pos)} 1/log2(r+2))   (0 when n_pos == 0)
+// labels: CSR over user ids, column ids sorted ascending within a row. out: [3, n_ks, Bu] (ndcg, recall, precision).
+// ---------------------------------------------------------------------------------------------------------------
+#define METRIC_MAX_KS 8
+struct KList { int n; int k[METRIC_MAX_KS]; };
+
+__global__ void rank_metrics_kernel(const int* __restrict__ topk, int kmax, const long* __restrict__ u_idx,
+                                    const long* __restrict__ indptr, const int* __restrict__ indices, long Bu, KList ks,
+                                    float* __restrict__ out) {
+  const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (b >= Bu) return;
+  const long u = u_idx ? u_idx[b] : b;
+  const long beg = indptr[u], end = indptr[u + 1];
+  const int npos = (int)(end - beg);
+  float dcg = 0.f, idcg = 0.f;
+  int hits = 0, q = 0;
+  for (int r = 0; r < kmax && q < ks.n; ++r) {
+    const int item = topk[b * kmax + r];
+    long lo = beg, hi = end;
+    while (lo < hi) {
+      const long mid = (lo + hi) >> 1;
+      if (indices[mid] < item) lo = mid + 1; else hi = mid;
+    }
+    const float disc = 1.f / log2f((float)(r + 2));
+    if (lo < end && indices[lo] == item) { ++hits; dcg += disc; }
+    if (r < npos) idcg += disc;
+    while (q < ks.n && ks.k[q] == r + 1) {
+      const float nd = npos > 0 ? fminf(dcg / idcg, 1.f) : 0.f;
+      out[(0 * ks.n + q) * Bu + b] = nd;
+      out[(1 * ks.n + q) * Bu + b] = npos > 0 ? (float)hits / (float)npos : 0.f;
+      out[(2 * ks.n + q) * Bu + b] = (float)hits / (float)ks.k[q];
+      ++q;
+    }
+  }
+}
+
+extern "C" int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const long* label_indptr,
+                                const int* label_indices, long Bu, const int* ks, int n_ks, float* out, void* stream) {
+  SBR_REQUIRE(n_ks >= 1 && n_ks <= METRIC_MAX_KS, "sbr_rank_metrics: n_ks=%d outside [1, %d]", n_ks, METRIC_MAX_KS);
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(topk_idx && label_indptr && label_indices && ks && out, "sbr_rank_metrics: null operand");
+  KList kl;
+  kl.n = n_ks;
+  for (int i = 0; i < n_ks; ++i) {
+    SBR_REQUIRE(ks[i] >= 1 && ks[i] <= kmax && (i == 0 || ks[i] > ks[i - 1]), "sbr_rank_metrics: ks must be ascending and <= kmax");
+    kl.k[i] = ks[i];
+  }
+  rank_metrics_kernel<<<sbr_cdiv(Bu, 256), 256, 0, (hipStream_t)stream>>>(topk_idx, kmax, u_idx, label_indptr, label_indices, Bu, kl, out);
+  SBR_CHECK_LAUNCH("sbr_rank_metrics");
+  return SBR_OK;
+}

@@ -1,0 +1,131 @@
+"""Dataset views and loaders on the host side of the hot path.
+
+* ``SyntheticDataset`` generates the synthetic workloads of SURVEY.md §8(d) / BASELINE.json (no dataset can be fetched
+  offline) and exposes exactly the attributes the plugin reads from the reference's datasets
+  (algorithms/sgd_alg.py:2021-2067, eval/eval.py:209,219, data/dataset.py:325-453).
+* ``NegativeSamplingDataLoader`` yields the same ``(u_idxs i64 [B], i_idxs i64 [B, 1+n_neg], labels f64)`` batches as the
+  reference's default loader (data/dataloader.py:134-198 with ``shuffle=True``), bit-exactly for the same seeds, using the
+  vectorised collate of sampling.py.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .features import HostFeature
+from .sampling import PositiveIndex, loader_epoch_order, recbole_negative_collate, uniform_negative_collate
+
+
+def synthetic_interactions(n_users: int, n_items: int, nnz: int, seed: int = 0) -> sp.csr_matrix:
+    """Per-user degree from a log-normal scaled to the target density, items uniform without replacement per user."""
+    rng = np.random.default_rng(seed)
+    deg = rng.lognormal(mean=0., sigma=1., size=n_users)
+    deg = np.maximum(1, np.round(deg / deg.sum() * nnz)).astype(np.int64)
+    deg = np.minimum(deg, max(1, n_items // 2))
+    rows = np.repeat(np.arange(n_users, dtype=np.int64), deg)
+    cols = rng.integers(0, n_items, size=rows.size)
+    m = sp.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(n_users, n_items))
+    m.sum_duplicates()
+    m.data[:] = 1
+    m.sort_indices()
+    return m
+
+
+class SyntheticDataset:
+    def __init__(self, n_users: int, n_items: int, nnz: int, item_dense: Dict[str, int] = None,
+                 item_tags: Dict[str, tuple] = None, user_categorical: Dict[str, int] = None, seed: int = 0,
+                 n_negative_samples: int = 10, negative_sampling_strategy: str = 'uniform_recbole',
+                 holdout_per_user: int = 0):
+        self.n_users, self.n_items = n_users, n_items
+        inter = synthetic_interactions(n_users, n_items, nnz, seed)
+        self.holdout = None
+        if holdout_per_user > 0:
+            # last `holdout_per_user` items of each user (>= 2 interactions) become the evaluation labels
+            rng = np.random.default_rng(seed + 7)
+            lil_rows, lil_cols = [], []
+            keep = inter.copy().tolil()
+            for u in range(n_users):
+                cols = inter.indices[inter.indptr[u]:inter.indptr[u + 1]]
+                if len(cols) > holdout_per_user:
+                    h = rng.choice(cols, size=holdout_per_user, replace=False)
+                    lil_rows += [u] * len(h)
+                    lil_cols += h.tolist()
+            self.holdout = sp.csr_matrix((np.ones(len(lil_rows), dtype=np.int8), (lil_rows, lil_cols)), shape=inter.shape)
+            inter = (inter - self.holdout).tocsr()
+            inter.eliminate_zeros()
+        self.interaction_matrix = inter.tocoo()
+        self.user_sampling_matrix = inter
+        self.user_sampling_matrix_train = inter
+        self.item_sampling_matrix_train = sp.csr_matrix(inter.T)
+        self.items_in_split = np.arange(n_items)
+        self.users_in_split = np.arange(n_users)
+        self.n_items_in_split, self.n_users_in_split = n_items, n_users
+        self.is_cold_start_user = self.is_cold_start_item = False
+        self.n_negative_samples = n_negative_samples
+        self.negative_sampling_strategy = negative_sampling_strategy
+        rng = np.random.default_rng(seed + 1)
+        self.item_features, self.user_features = {}, {}
+        for name, dim in (item_dense or {}).items():
+            self.item_features[name] = HostFeature(name, 'dense', rng.standard_normal((n_items, dim), dtype=np.float32))
+        rng = np.random.default_rng(seed + 2)
+        for name, (n_tags, max_tags) in (item_tags or {}).items():
+            cnt = rng.integers(1, max_tags + 1, size=n_items)
+            tags = np.full((n_items, max_tags), n_tags, dtype=np.int64)
+            for j in range(max_tags):
+                draw = rng.integers(0, n_tags, size=n_items)
+                tags[:, j] = np.where(j < cnt, draw, n_tags)
+            self.item_features[name] = HostFeature(name, 'tag', tags, n_categories=n_tags)
+        for name, n_cat in (user_categorical or {}).items():
+            self.user_features[name] = HostFeature(name, 'categorical', rng.integers(0, n_cat, size=n_users), n_categories=n_cat)
+
+    def __len__(self):
+        return self.interaction_matrix.nnz
+
+    def eval_view(self):
+        """FullEvalDataset-like view (data/dataset.py:399-453): labels = held-out interactions, exclusions = train."""
+        assert self.holdout is not None, 'build the dataset with holdout_per_user > 0'
+        return SimpleNamespace(n_users=self.n_users, n_items=self.n_items, items_in_split=self.items_in_split,
+                               users_in_split=self.users_in_split, n_items_in_split=self.n_items,
+                               n_users_in_split=self.n_users, user_sampling_matrix=self.holdout,
+                               exclude_data=self.user_sampling_matrix_train.astype(bool),
+                               user_features=self.user_features, item_features=self.item_features)
+
+
+class NegativeSamplingDataLoader:
+    """Default training loader of the reference (data/dataloader.py:134-198 + shuffle) with the vectorised collate."""
+
+    def __init__(self, dataset, batch_size: int = 256, shuffle: bool = True, strategy: Optional[str] = None,
+                 rank: int = 0, world: int = 1, max_batches: Optional[int] = None):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.strategy = strategy or dataset.negative_sampling_strategy
+        if self.strategy not in ('uniform_recbole', 'uniform'):
+            raise ValueError(f'sampling strategy {self.strategy} not supported for dataloader sampling!')
+        self.n_neg = dataset.n_negative_samples
+        coo = dataset.interaction_matrix
+        self.rows, self.cols = coo.row.astype(np.int64), coo.col.astype(np.int64)
+        self.positives = PositiveIndex(dataset.user_sampling_matrix)
+        self.rank, self.world, self.max_batches = rank, world, max_batches
+
+    def __len__(self):
+        n = (len(self.rows) + self.batch_size - 1) // self.batch_size
+        return n if self.max_batches is None else min(n, self.max_batches)
+
+    def __iter__(self):
+        n = len(self.rows)
+        order = loader_epoch_order(n) if self.shuffle else np.arange(n)
+        for b in range(len(self)):
+            sel = order[b * self.batch_size:(b + 1) * self.batch_size]
+            if self.strategy == 'uniform_recbole':
+                u, i, l = recbole_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.items_in_split,
+                                                   self.positives)
+            else:
+                u, i, l = uniform_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.n_items,
+                                                   self.positives)
+            # data parallel: every rank consumes the same global streams and keeps its slice (parallel.shard_batch)
+            if self.world > 1:
+                u, i, l = u[self.rank::self.world], i[self.rank::self.world], l[self.rank::self.world]
+            yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)

@@ -1,0 +1,158 @@
+"""Full-catalogue evaluation with the reference's hooks: ``FullEvaluator`` and ``evaluate_recommender_algorithm``
+(eval/eval.py:20-168, 171-227).
+
+The reference scores a user batch against all items (``einsum('be,ce->bc')``), sets ``out[exclude_data[u]] = -inf`` from a
+host-densified CSR mask, and hands the dense [Bu, I_s] logits plus dense label rows to the third-party ``rmet.calculate``.
+Here the exclusion CSR and the label CSR are resident on the device; per user batch the engine runs either
+  * ``scorer='fp32'``      : fp32-MFMA GEMM -> CSR mask kernel -> exact radix-select top-k, or
+  * ``scorer='fp16_fused'``: the fused fp16-MFMA score+mask+top-k kernel (scores never written),
+followed by the ranking-metric kernel (NDCG / recall / precision as defined in eval/metrics.py:4-105; ``rmet`` itself is
+absent offline, so w.r.t. ``rmet`` the metric arithmetic is parity-unpinned). ``eval_batch`` keeps the reference's
+dense-logits entry point for callers that already hold a score matrix.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import ops
+
+SUPPORTED_METRICS = ('ndcg', 'precision', 'recall', 'f_score', 'hitrate', 'coverage')
+
+
+class _Cfg:
+    def __init__(self, top_k=(1, 3, 5, 10, 20, 50, 100), metrics=SUPPORTED_METRICS, calculate_std=True):
+        self.top_k, self.metrics, self.calculate_std = list(top_k), list(metrics), calculate_std
+
+
+def _csr_to_device(m: sp.spmatrix, device):
+    m = sp.csr_matrix(m)
+    m.sort_indices()
+    m.eliminate_zeros()
+    return (torch.from_numpy(m.indptr.astype(np.int64)).to(device), torch.from_numpy(m.indices.astype(np.int32)).to(device))
+
+
+class FullEvaluator:
+    """eval/eval.py:20-168 — accumulates per-user metric arrays over batches; ``get_results`` averages them."""
+
+    def __init__(self, config=None, evaluator_name: str = None, dataset=None):
+        self.config = config if config is not None else _Cfg()
+        self.name = evaluator_name
+        self.dataset = dataset
+        invalid = set(self.config.metrics) - set(SUPPORTED_METRICS)
+        if invalid:
+            raise ValueError(f'Metric(s) {invalid} are not supported. Select metrics from {SUPPORTED_METRICS}.')
+        self._ks = sorted(set(int(k) for k in self.config.top_k))
+        self._labels_dev = None
+        self._reset()
+
+    def _reset(self):
+        self._results = defaultdict(list)
+        self._topk = []
+
+    def _key(self, metric, k):
+        base = f'{metric}@{k}'
+        return f'{self.name}/{base}' if self.name else base
+
+    def _labels(self, device):
+        if self._labels_dev is None or self._labels_dev[0].device != torch.device(device):
+            ds = self.dataset
+            lab = sp.csr_matrix(ds.user_sampling_matrix)[:, np.asarray(ds.items_in_split)]
+            self._labels_dev = _csr_to_device(lab, device)
+        return self._labels_dev
+
+    def eval_topk(self, u_idxs: torch.Tensor, topk_idx: torch.Tensor):
+        """Engine entry point: per-user top-k item positions (int32 [Bu, kmax], kmax >= max(top_k))."""
+        kmax = topk_idx.shape[1]
+        ks = [k for k in self._ks if k <= kmax]
+        indptr, indices = self._labels(topk_idx.device)
+        m = ops.rank_metrics(topk_idx.contiguous(), u_idxs.long().contiguous(), indptr, indices, ks)   # [3, n_ks, Bu]
+        for qi, k in enumerate(ks):
+            nd, rc, pr = m[0, qi], m[1, qi], m[2, qi]
+            if 'ndcg' in self.config.metrics:
+                self._results[self._key('ndcg', k)].append(nd)
+            if 'recall' in self.config.metrics:
+                self._results[self._key('recall', k)].append(rc)
+            if 'precision' in self.config.metrics:
+                self._results[self._key('precision', k)].append(pr)
+            if 'hitrate' in self.config.metrics:
+                self._results[self._key('hitrate', k)].append((pr > 0).float())
+            if 'f_score' in self.config.metrics:
+                den = pr + rc
+                self._results[self._key('f_score', k)].append(torch.where(den > 0, 2 * pr * rc / den.clamp_min(1e-30), den))
+        if 'coverage' in self.config.metrics:
+            self._topk.append(topk_idx)
+
+    def eval_batch(self, u_idxs: torch.Tensor, logits: torch.Tensor, y_true: torch.Tensor = None):
+        """Reference entry point (eval.py:121-138): dense [Bu, I_s] logits (already masked). ``y_true`` is ignored when the
+        evaluator was built with a dataset (labels come from the resident CSR); without a dataset the dense rows are used."""
+        if y_true is not None and logits.shape != y_true.shape:
+            raise AttributeError(f'logits and true labels must have the same shape ({logits.shape} != {y_true.shape})')
+        if len(u_idxs) != len(logits):
+            raise AttributeError('assumed batch size is not equal for user indices, logits and true labels')
+        kmax = min(max(self._ks), logits.shape[1])
+        _, idx = ops.topk_rows(logits.float().contiguous(), kmax)
+        if self.dataset is None:
+            lab = sp.csr_matrix(y_true.detach().cpu().numpy() > 0)
+            self._labels_dev = _csr_to_device(lab, logits.device)
+            self.eval_topk(torch.arange(len(u_idxs), device=logits.device), idx)
+            self._labels_dev = None
+        else:
+            self.eval_topk(u_idxs, idx)
+
+    def get_results(self, return_raw_results: bool = False):
+        raw = {k: torch.cat(v).cpu().numpy() for k, v in self._results.items()}
+        metrics = {k: float(v.mean()) for k, v in raw.items()}
+        if getattr(self.config, 'calculate_std', False):
+            metrics.update({f'{k}_std': float(v.std()) for k, v in raw.items()})
+        if self._topk:
+            top = torch.cat(self._topk)
+            n_items = self.dataset.n_items_in_split if self.dataset is not None else int(top.max()) + 1
+            for k in self._ks:
+                if k <= top.shape[1]:
+                    metrics[self._key('coverage', k)] = torch.unique(top[:, :k]).numel() / n_items
+        metrics = {k: metrics[k] for k in sorted(metrics)}
+        self._reset()
+        return (metrics, raw) if return_raw_results else metrics
+
+
+def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, device='cuda', return_raw=False, verbose=False,
+                                   scorer: str = 'fp32'):
+    """eval/eval.py:171-227 (SGD branch :203-222). ``eval_loader`` only has to expose ``dataset`` and ``batch_size``."""
+    dataset = eval_loader.dataset
+    for attr in ('items_in_split', 'users_in_split', 'exclude_data'):
+        if not hasattr(dataset, attr):
+            raise ValueError("Dataset underlying loader must be of type 'FullEvaluatorDataset'")
+    alg.eval()
+    kmax = max(evaluator._ks)
+    with torch.no_grad():
+        items = torch.as_tensor(np.asarray(dataset.items_in_split)).to(device)
+        i_repr = alg.get_item_representations(items)                          # once: [I_s, D]
+        kmax = min(kmax, i_repr.shape[0])
+        excl = getattr(dataset, '_excl_dev', None)
+        if excl is None or excl[0].device != i_repr.device:
+            excl = _csr_to_device(dataset.exclude_data, i_repr.device)
+            try:
+                dataset._excl_dev = excl
+            except Exception:
+                pass
+        users = np.asarray(dataset.users_in_split)
+        bs = int(getattr(eval_loader, 'batch_size', 256) or 256)
+        i16 = ops.cast_f16(i_repr) if scorer == 'fp16_fused' else None
+        for s in range(0, len(users), bs):
+            u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
+            u_repr = alg.get_user_representations(u_idxs)
+            if scorer == 'fp16_fused':
+                _, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1])
+            elif scorer == 'fp32':
+                out = alg.combine_user_item_representations(u_repr, i_repr)
+                ops.mask_scores_(out, u_idxs, excl[0], excl[1])
+                _, idx = ops.topk_rows(out, kmax)
+            else:
+                raise ValueError(f'unknown scorer {scorer!r}')
+            evaluator.eval_topk(u_idxs, idx)
+    return evaluator.get_results(return_raw_results=return_raw)

@@ -1,0 +1,396 @@
+"""torch.autograd wrappers around the C-ABI kernels (include/sibrar_hip.h).
+
+PyTorch is used for device memory, streams and the autograd tape only; every forward/backward computation is a HIP
+kernel of libsibrar_hip.so. All tensors are fp32 / contiguous CUDA tensors unless stated otherwise. There is no CPU path:
+calling any op with CPU tensors raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from ._lib import call, ptr, stream
+
+ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'selu': 4}
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+NORM_EPS = 1e-12
+
+
+def act_code(act) -> int:
+    if isinstance(act, torch.nn.Module):
+        act = act.__class__.__name__.lower()
+    if act not in ACT_CODES:
+        raise ValueError(f'unsupported activation {act!r}')
+    return ACT_CODES[act]
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('sibrar HIP ops need CUDA(HIP) tensors; there is no CPU fallback in this package')
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- raw kernel helpers (no autograd) -------------------------------------------------------------------------------
+def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, act=0, atomic=0):
+    call('sbr_gemm_f32', mode, ptr(A), lda, ptr(a_idx), ptr(B), ldb, ptr(b_idx), ptr(bias), ptr(C), ldc, ptr(c_idx),
+         M, N, K, act, atomic, stream())
+
+
+def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None):
+    """out[ci(m)] = act(x[ai(m)] @ W^T + bias). W: [N, K] with arbitrary row stride (column-major weights are handled by
+    the caller through csr kernels, not here)."""
+    M = n_rows if n_rows is not None else (a_idx.numel() if a_idx is not None else x.shape[0])
+    N, K = W.shape
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    gemm(0, x, x.stride(0), a_idx, W, W.stride(0), None, bias, out, out.stride(0), c_idx, M, N, K, act, 0)
+    return out
+
+
+def matmul_nn(dz, W, a_idx=None, n_rows=None):
+    """dz[ai(m)] @ W, W: [K, N] row-major."""
+    M = n_rows if n_rows is not None else (a_idx.numel() if a_idx is not None else dz.shape[0])
+    K, N = W.shape
+    out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
+    gemm(1, dz, dz.stride(0), a_idx, W, W.stride(0), None, None, out, out.stride(0), None, M, N, K, 0, 0)
+    return out
+
+
+def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None):
+    """sum_r dz[ai(r)]^T x[bi(r)] -> [dz.shape[1], x.shape[1]]."""
+    R = n_rows if n_rows is not None else dz.shape[0]
+    M, N = dz.shape[1], x.shape[1]
+    out = torch.zeros(M, N, device=dz.device, dtype=torch.float32)
+    if R > 0:
+        gemm(2, dz, dz.stride(0), a_idx, x, x.stride(0), b_idx, None, out, out.stride(0), None, M, N, R, 0, 1)
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    n, C = x.shape
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(C, device=x.device, dtype=torch.float64)
+    call('sbr_colsum', ptr(x), x.stride(0), n, C, ptr(out), ptr(ws), stream())
+    return out
+
+
+def act_grad(dy, y, act: int, idx=None, n_rows=None):
+    """dz[j] = dy[idx[j]] * act'(y[idx[j]]) (compact [n, C])."""
+    n = n_rows if n_rows is not None else (idx.numel() if idx is not None else dy.shape[0])
+    C = dy.shape[1]
+    dz = torch.empty(n, C, device=dy.device, dtype=torch.float32)
+    call('sbr_act_grad_gather', ptr(dy), ptr(y), dy.stride(0), ptr(idx), ptr(dz), C, n, C, act, stream())
+    return dz
+
+
+# ---- Linear (+ activation) ----------------------------------------------------------------------------------------------
+class LinearActFn(Function):
+    """y = act(x @ W^T + b) — nn.Linear + activation of modules/polylinear.py:51,63-72."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int):
+        _need_cuda(x, weight)
+        x = _f32c(x)
+        w = weight if weight.stride(1) == 1 else weight.contiguous()
+        y = linear_nt(x, w, bias, act)
+        ctx.act = act
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        dz = act_grad(dy, y, ctx.act) if ctx.act else dy
+        dx = matmul_nn(dz, w) if ctx.needs_input_grad[0] else None
+        dw = matmul_tn(dz, x) if ctx.needs_input_grad[1] else None
+        db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+# ---- BatchNorm1d (+ activation) ---------------------------------------------------------------------------------------
+class BatchNormActFn(Function):
+    """Train-mode BatchNorm1d over rows followed by an activation (polylinear.py:61-65; sgd_alg.py:1837)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, act: int):
+        _need_cuda(x, weight)
+        x = _f32c(x)
+        n, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(D, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(D, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * D, device=x.device, dtype=torch.float64)
+        call('sbr_bn_train_fwd', ptr(x), ptr(y), n, D, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+             ptr(num_batches_tracked), ptr(mean), ptr(rstd), ptr(ws), BN_EPS, BN_MOMENTUM, act, stream())
+        ctx.act = act
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches_tracked) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, D = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty(D, device=x.device, dtype=torch.float32)
+        db = torch.empty(D, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * D, device=x.device, dtype=torch.float64)
+        call('sbr_bn_train_bwd', ptr(dy), ptr(y), ptr(x), ptr(dx), n, D, ptr(weight), ptr(mean), ptr(rstd), ptr(dw), ptr(db),
+             ptr(ws), ctx.act, stream())
+        return dx, dw, db, None, None, None, None
+
+
+def batch_norm_eval(x, weight, bias, running_mean, running_var, act: int):
+    _need_cuda(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    call('sbr_bn_eval_fwd', ptr(x), ptr(y), x.shape[0], x.shape[1], ptr(weight), ptr(bias), ptr(running_mean),
+         ptr(running_var), BN_EPS, act, stream())
+    return y
+
+
+# ---- row normalisation, dropout, aggregation ---------------------------------------------------------------------------
+class L2NormalizeFn(Function):
+    """F.normalize(x, p=2, dim=-1) — sgd_alg.py:1873-1874."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        inv = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        call('sbr_l2norm_fwd', ptr(x), ptr(y), ptr(inv), x.shape[0], x.shape[1], NORM_EPS, stream())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        call('sbr_l2norm_bwd', ptr(dy), ptr(y), ptr(inv), ptr(dx), y.shape[0], y.shape[1], NORM_EPS, stream())
+        return dx
+
+
+class DropoutFn(Function):
+    """nn.Dropout(p) in training mode with a counter-based mask (seed, element index)."""
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int):
+        _need_cuda(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call('sbr_dropout', ptr(x), ptr(y), x.numel(), p, seed, stream())
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        call('sbr_dropout', ptr(dy), ptr(dx), dy.numel(), ctx.p, ctx.seed, stream())
+        return dx, None, None
+
+
+class AggregateFn(Function):
+    """mean / max over the k sampled modalities: [S, k, D] -> [S, D] (sgd_alg.py:27-31, 1861)."""
+
+    @staticmethod
+    def forward(ctx, e, mode: int):
+        _need_cuda(e)
+        e = _f32c(e)
+        S, k, D = e.shape
+        out = torch.empty(S, D, device=e.device, dtype=torch.float32)
+        arg = torch.empty(S, D, device=e.device, dtype=torch.uint8) if mode == 1 else None
+        call('sbr_aggregate_fwd', ptr(e), ptr(out), ptr(arg), S, k, D, mode, stream())
+        ctx.mode, ctx.shape = mode, (S, k, D)
+        ctx.save_for_backward(arg if arg is not None else torch.empty(0, device=e.device))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        S, k, D = ctx.shape
+        dout = _f32c(dout)
+        de = torch.empty(S, k, D, device=dout.device, dtype=torch.float32)
+        call('sbr_aggregate_bwd', ptr(dout), ptr(arg) if ctx.mode == 1 else None, ptr(de), S, k, D, ctx.mode, stream())
+        return de, None
+
+
+# ---- scorers ----------------------------------------------------------------------------------------------------------------
+class ScoreDotFn(Function):
+    """einsum('be,bce->bc') — sgd_alg.py:2114."""
+
+    @staticmethod
+    def forward(ctx, u, i):
+        _need_cuda(u, i)
+        u, i = _f32c(u), _f32c(i)
+        B, N, D = i.shape
+        out = torch.empty(B, N, device=u.device, dtype=torch.float32)
+        call('sbr_score_dot_fwd', ptr(u), ptr(i), ptr(out), B, N, D, stream())
+        ctx.save_for_backward(u, i)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, i = ctx.saved_tensors
+        g = _f32c(g)
+        B, N, D = i.shape
+        du = torch.empty_like(u) if ctx.needs_input_grad[0] else None
+        di = torch.empty_like(i) if ctx.needs_input_grad[1] else None
+        call('sbr_score_dot_bwd', ptr(g), ptr(u), ptr(i), ptr(du), ptr(di), B, N, D, stream())
+        return du, di
+
+
+class ScoreAllFn(Function):
+    """einsum('be,ce->bc') — sgd_alg.py:2109: all users of the batch against all item representations."""
+
+    @staticmethod
+    def forward(ctx, u, i):
+        _need_cuda(u, i)
+        u, i = _f32c(u), _f32c(i)
+        ctx.save_for_backward(u, i)
+        return linear_nt(u, i)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, i = ctx.saved_tensors
+        g = _f32c(g)
+        du = matmul_nn(g, i) if ctx.needs_input_grad[0] else None
+        di = matmul_tn(g, u) if ctx.needs_input_grad[1] else None
+        return du, di
+
+
+# ---- losses -------------------------------------------------------------------------------------------------------------------
+LOSS_CODES = {'bce': 0, 'bpr': 1, 'sampled_softmax': 2}
+
+
+class RecLossFn(Function):
+    """train/rec_losses.py:43-113. Returns a float64 scalar for bce / bpr (float64 labels promote the computation in the
+    reference) and a float32 scalar for sampled softmax."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, kind: int, scale: float, shift: float):
+        _need_cuda(logits)
+        logits = _f32c(logits)
+        B, N = logits.shape
+        lab = None
+        if kind != 2:
+            lab = labels.to(device=logits.device, dtype=torch.float64).contiguous()
+        out = torch.empty((), device=logits.device, dtype=torch.float64)
+        call('sbr_rec_loss_fwd', kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(out), stream())
+        ctx.args = (kind, scale, shift)
+        ctx.save_for_backward(logits, lab if lab is not None else torch.empty(0, device=logits.device))
+        return out if kind != 2 else out.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lab = ctx.saved_tensors
+        kind, scale, shift = ctx.args
+        B, N = logits.shape
+        g = g.contiguous()
+        d = torch.empty_like(logits)
+        call('sbr_rec_loss_bwd', kind, ptr(logits), ptr(lab) if kind != 2 else None, B, N, scale, shift, ptr(g),
+             1 if g.dtype == torch.float64 else 0, ptr(d), stream())
+        return d, None, None, None, None
+
+
+class InfoNCEFn(Function):
+    """train/regularization_losses.py:14-43 on two [G, N, D] views that may be strided slices of one [G*N, 2, D] tensor."""
+
+    @staticmethod
+    def forward(ctx, e, tau: float, mean: bool, G: int, N: int):
+        # e: [G*N, 2, D] contiguous; a = e[:, 0], b = e[:, 1]
+        _need_cuda(e)
+        e = _f32c(e)
+        D = e.shape[-1]
+        out = torch.empty((), device=e.device, dtype=torch.float64)
+        scale = 1.0 / (G * N) if mean else 1.0
+        a, b = e[:, 0], e[:, 1]
+        call('sbr_infonce_fwd', a.data_ptr(), b.data_ptr(), 2 * D, G, N, D, tau, scale, ptr(out), stream())
+        ctx.args = (tau, scale, G, N, D)
+        ctx.save_for_backward(e)
+        return out.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        (e,) = ctx.saved_tensors
+        tau, scale, G, N, D = ctx.args
+        g = g.float().contiguous()
+        de = torch.empty_like(e)
+        call('sbr_infonce_bwd', e[:, 0].data_ptr(), e[:, 1].data_ptr(), 2 * D, G, N, D, tau, scale, ptr(g),
+             de[:, 0].data_ptr(), de[:, 1].data_ptr(), 2 * D, stream())
+        return de, None, None, None, None
+
+
+def infonce_max_n() -> int:
+    from ._lib import lib
+    return lib().sbr_infonce_max_n()
+
+
+# ---- evaluation helpers -----------------------------------------------------------------------------------------------------
+def mask_scores_(scores: torch.Tensor, u_idx: torch.Tensor, excl_indptr: torch.Tensor, excl_indices: torch.Tensor):
+    _need_cuda(scores)
+    call('sbr_mask_scores', ptr(scores), scores.stride(0), ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), scores.shape[0], stream())
+    return scores
+
+
+def topk_rows(scores: torch.Tensor, k: int):
+    _need_cuda(scores)
+    Bu, I = scores.shape
+    val = torch.empty(Bu, k, device=scores.device, dtype=torch.float32)
+    idx = torch.empty(Bu, k, device=scores.device, dtype=torch.int32)
+    call('sbr_topk_rows', ptr(scores), scores.stride(0), Bu, I, k, ptr(val), ptr(idx), stream())
+    return val, idx
+
+
+def rank_metrics(topk_idx: torch.Tensor, u_idx, label_indptr, label_indices, ks: Sequence[int]):
+    _need_cuda(topk_idx)
+    Bu, kmax = topk_idx.shape
+    import ctypes
+    ks_arr = (ctypes.c_int * len(ks))(*ks)
+    out = torch.empty(3, len(ks), Bu, device=topk_idx.device, dtype=torch.float32)
+    call('sbr_rank_metrics', ptr(topk_idx), kmax, ptr(u_idx), ptr(label_indptr), ptr(label_indices), Bu,
+         ctypes.cast(ks_arr, ctypes.c_void_p), len(ks), ptr(out), stream())
+    return out
+
+
+def cast_f16(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    x = _f32c(x)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+    call('sbr_cast_f32_to_f16', ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, excl_indptr=None, excl_indices=None,
+                   item_offset: int = 0):
+    _need_cuda(u16, i16)
+    Bu, D = u16.shape
+    I = i16.shape[0]
+    val = torch.empty(Bu, k, device=u16.device, dtype=torch.float32)
+    idx = torch.empty(Bu, k, device=u16.device, dtype=torch.int32)
+    call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), item_offset, k,
+         ptr(val), ptr(idx), None, 0, stream())
+    return val, idx
+
+
+# ---- optimizer steps ----------------------------------------------------------------------------------------------------------
+def adam_step(kind: int, p, g, m, v, lr, b1, b2, eps, wd, step: int):
+    call('sbr_adam_step', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, wd, step, stream())
+
+
+def adagrad_step(p, g, s, lr, eps, wd):
+    call('sbr_adagrad_step', ptr(p), ptr(g), ptr(s), p.numel(), lr, eps, wd, stream())

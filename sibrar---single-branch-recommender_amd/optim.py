@@ -1,0 +1,100 @@
+"""Fused dense optimizers over ONE flat fp32 parameter buffer (train/trainer.py:62-68 builds a dense torch optimizer over
+``model.parameters()``; every element of every embedding table is decayed and updated on every step).
+
+``FlatParameters`` re-homes all parameters of a module into one contiguous buffer (parameters become views, strides kept,
+so the column-major CSR projector weight stays column-major) and gives them a matching flat gradient buffer. One kernel
+launch then updates the whole model, ``zero_grad`` is one memset, and the data-parallel gradient exchange is a single RCCL
+all-reduce of the flat gradient buffer (parallel.py).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class FlatParameters:
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('module has no trainable parameters')
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatParameters needs the module on a CUDA(HIP) device')
+        self.params = params
+        sizes = [p.numel() for p in params]
+        # 64-element (256 B) alignment of every segment
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += (s + 63) // 64 * 64
+        self.offsets, self.sizes, self.total = offs, sizes, total
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, o, s in zip(params, offs, sizes):
+            self._rehome(p, self.flat, o, s, is_grad=False)
+            self._rehome(p, self.grad, o, s, is_grad=True)
+
+    @staticmethod
+    def _view_like(p: torch.Tensor, buf: torch.Tensor, off: int, n: int) -> torch.Tensor:
+        # dense, non-overlapping (possibly permuted) layouts only
+        return torch.as_strided(buf, p.shape, p.stride(), off)
+
+    def _rehome(self, p, buf, off, n, is_grad):
+        dense = sorted(zip(p.stride(), p.shape), reverse=True)
+        expect, ok = 1, True
+        for st, sh in reversed(dense):
+            if sh != 1 and st != expect:
+                ok = False
+            expect *= sh
+        if not ok:
+            raise ValueError('parameter layout is not dense; cannot flatten')
+        view = self._view_like(p, buf, off, n)
+        if is_grad:
+            p.grad = view
+        else:
+            view.copy_(p.data)
+            p.data = view
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o, s in zip(self.params, self.offsets, self.sizes):   # autograd may have replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self._view_like(p, self.grad, o, s)
+
+
+class FusedOptimizer:
+    """AdamW / Adam / Adagrad with torch's defaults (betas 0.9/0.999, eps 1e-8; Adagrad eps 1e-10), one launch per step."""
+
+    def __init__(self, module: nn.Module, name: str = 'adamw', lr: float = 1e-3, weight_decay: float = 0.):
+        if name not in ('adamw', 'adam', 'adagrad'):
+            raise KeyError(name)
+        self.name, self.lr, self.wd = name, lr, weight_decay
+        self.fp = FlatParameters(module)
+        self.step_count = 0
+        n, dev = self.fp.total, self.fp.flat.device
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32) if name != 'adagrad' else None
+
+    def _sync_grads(self):
+        """Gradients that autograd produced as fresh tensors (instead of accumulating into the flat views) are copied in."""
+        fp = self.fp
+        for p, o, s in zip(fp.params, fp.offsets, fp.sizes):
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() != fp.grad.data_ptr() + 4 * o:
+                fp._view_like(p, fp.grad, o, s).copy_(p.grad)
+
+    def step(self):
+        self._sync_grads()
+        self.step_count += 1
+        fp = self.fp
+        if self.name == 'adagrad':
+            ops.adagrad_step(fp.flat, fp.grad, self.m, self.lr, 1e-10, self.wd)
+        else:
+            ops.adam_step(0 if self.name == 'adamw' else 1, fp.flat, fp.grad, self.m, self.v, self.lr, 0.9, 0.999, 1e-8,
+                          self.wd, self.step_count)
+
+    def zero_grad(self):
+        self.fp.zero_grad()

@@ -1,0 +1,127 @@
+"""Host-side samplers that reproduce the reference's random streams bit-exactly, vectorised per batch.
+
+* ``sample_modality_ids`` replaces the per-row ``rng.choice(a, k, replace=False)`` loop of
+  utilities/utils.py:60-90 (row_wise_sample), called from algorithms/sgd_alg.py:1904-1927 with the entity's
+  ``np.random.default_rng(sampling_seed)`` (sgd_alg.py:1848). For the small populations used here numpy's
+  ``Generator.choice(n, k, replace=False)`` is Floyd's algorithm followed by a Fisher-Yates pass over the k results, every
+  bounded draw being one 32-bit Lemire draw from the PCG64 stream; one vectorised ``rng.integers`` call with per-element
+  bounds consumes the stream in exactly the same order.
+* ``recbole_negative_collate`` replaces data/dataloader.py:154-198 (the default ``uniform_recbole`` collate): identical
+  ``np.random.choice(items_in_split, n, replace=True)`` calls on the global legacy generator, with the Python
+  ``v in positives`` loop replaced by a sorted-key membership test.
+* ``loader_epoch_order`` reproduces the index order of ``DataLoader(shuffle=True)``.
+All functions return integer arrays; the parity bar is exact equality with the oracle / golden streams.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def sample_modality_ids(rng: np.random.Generator, n_rows: int, n_mod: int, k: int) -> np.ndarray:
+    """-> int8 [n_rows, k] of positions into the ordered modality list; same stream consumption as n_rows calls of
+    ``rng.choice(n_mod, k, replace=False)``."""
+    if k > n_mod:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    if k == 1:
+        return rng.integers(0, n_mod, size=(n_rows, 1)).astype(np.int8)
+    if k == 2:
+        hi = np.tile(np.array([n_mod - 1, n_mod, 2], dtype=np.int64), n_rows)
+        w = rng.integers(0, hi).reshape(n_rows, 3)
+        v0 = w[:, 0]
+        v1 = np.where(w[:, 1] == v0, n_mod - 1, w[:, 1])          # Floyd: a repeated value is replaced by j = n-1
+        swap = w[:, 2] == 0                                        # Fisher-Yates step i=1: swap with position 0
+        first = np.where(swap, v1, v0)
+        second = np.where(swap, v0, v1)
+        return np.stack([first, second], axis=1).astype(np.int8)
+    # general (unused by the shipped configs): literal per-row calls
+    return np.stack([rng.choice(n_mod, k, replace=False) for _ in range(n_rows)]).astype(np.int8)
+
+
+def sample_modalities(rng, order: Sequence[str], n_rows: int, reg_type: str, central: Optional[str] = None) -> np.ndarray:
+    """Modality positions (into ``order``) for ``n_rows`` index slots — sgd_alg.py:1912-1927."""
+    n = len(order)
+    if reg_type == 'no_regularization':
+        return sample_modality_ids(rng, n_rows, n, 1)
+    if reg_type == 'pairwise_single':
+        return sample_modality_ids(rng, n_rows, n, 2)
+    if reg_type == 'central_modality':
+        if central not in order:
+            raise ValueError(f'central item "{central}" must be contained in "a"')
+        c = list(order).index(central)
+        others = np.array([i for i in range(n) if i != c], dtype=np.int8)
+        pick = sample_modality_ids(rng, n_rows, n - 1, 1)[:, 0]
+        return np.stack([np.full(n_rows, c, dtype=np.int8), others[pick]], axis=1)
+    raise ValueError(f'Embedding regularization "{reg_type}" is not yet supported.')
+
+
+def loader_epoch_order(n: int) -> np.ndarray:
+    """Index order of one epoch of ``DataLoader(shuffle=True, num_workers=0)``: creating the iterator draws the int64
+    ``_base_seed`` from torch's default generator, RandomSampler draws another int64 to seed its private generator, then
+    ``torch.randperm(n, generator)``."""
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g).numpy()
+
+
+class PositiveIndex:
+    """Sorted (user, item) keys of the split's interaction matrix for O(log nnz) membership tests."""
+
+    def __init__(self, csr):
+        csr = csr.tocsr()
+        self.n_items = int(csr.shape[1])
+        rows = np.repeat(np.arange(csr.shape[0], dtype=np.int64), np.diff(csr.indptr))
+        self.keys = np.sort(rows * self.n_items + csr.indices.astype(np.int64))
+
+    def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
+        q = users.astype(np.int64) * self.n_items + items.astype(np.int64)
+        pos = np.searchsorted(self.keys, q)
+        pos = np.minimum(pos, len(self.keys) - 1) if len(self.keys) else pos
+        return (self.keys[pos] == q) if len(self.keys) else np.zeros(len(q), dtype=bool)
+
+
+def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, items_in_split: np.ndarray,
+                             positives: PositiveIndex):
+    """data/dataloader.py:154-198 with the same global-RNG calls: draw all B*n_neg slots, redraw only the colliding ones
+    (in ascending slot order) until none collides. Returns (users i64 [B], items i64 [B, 1+n_neg], labels f64)."""
+    user_idx = np.asarray(user_idx).astype(np.int64)
+    b = len(user_idx)
+    total = b * n_neg
+    values = np.zeros(total, dtype=np.int64)
+    slot_user = np.tile(user_idx, n_neg)
+    todo = np.arange(total)
+    while len(todo) > 0:
+        values[todo] = np.random.choice(items_in_split, size=len(todo), replace=True)
+        todo = todo[positives.contains(slot_user[todo], values[todo])]
+    neg = values.reshape(n_neg, -1).T
+    items = np.column_stack([pos_item_idx, neg]).astype(np.int64)
+    labels = np.zeros_like(items, dtype=float)
+    n_pos = pos_item_idx.shape[-1] if np.ndim(pos_item_idx) > 1 else 1
+    labels[:, :n_pos] = 1.
+    return user_idx, items, labels
+
+
+def uniform_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, n_items: int,
+                             positives: PositiveIndex):
+    """data/dataloader.py:93-131 (TrainDataLoader + NegativeSampler 'uniform'): ``np.random.randint(0, n_items, m)`` refills
+    the still-colliding slots (row-major order) until none collides."""
+    user_idx = np.asarray(user_idx).astype(np.int64)
+    b = len(user_idx)
+    neg = np.empty((b, n_neg), dtype=np.int64)
+    mask = np.ones((b, n_neg), dtype=bool)
+    users2d = np.repeat(user_idx[:, None], n_neg, axis=1)
+    while True:
+        m = int(mask.sum())
+        if m == 0:
+            break
+        neg[mask] = np.random.randint(0, high=n_items, size=m)
+        mask = positives.contains(users2d.reshape(-1), neg.reshape(-1)).reshape(b, n_neg)
+    items = np.column_stack([pos_item_idx, neg]).astype(np.int64)
+    labels = np.zeros_like(items, dtype=float)
+    n_pos = pos_item_idx.shape[-1] if np.ndim(pos_item_idx) > 1 else 1
+    labels[:, :n_pos] = 1.
+    return user_idx, items, labels

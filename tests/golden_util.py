@@ -108,3 +108,33 @@ def bn_shadowed_biases(keys):
         if ms and i == n_layers - 1 and f'{ms.group(1)}{int(ms.group(2)) + 1}.running_mean' in keys:
             out.update([k, f'{ms.group(1)}{int(ms.group(2)) + 1}.running_mean'])
     return out
+
+
+def host_dataset(w):
+    """The golden 'world' as a dataset namespace for the product plugin (sibrar_amd.SingleBranchNet)."""
+    from types import SimpleNamespace
+    import sibrar_amd as S
+    item = {
+        'text': S.HostFeature('text', 'dense', w['text']),
+        'audio': S.HostFeature('audio', 'dense', w['audio']),
+        'genres': S.HostFeature('genres', 'tag', w['genres'], n_categories=w['genres_ntags']),
+    }
+    user = {
+        'gender': S.HostFeature('gender', 'categorical', w['gender'], n_categories=w['gender_ncat']),
+        'age': S.HostFeature('age', 'categorical', w['age'], n_categories=w['age_ncat']),
+    }
+    return SimpleNamespace(n_users=U, n_items=I, user_features=user, item_features=item,
+                           user_sampling_matrix_train=w['inter'], item_sampling_matrix_train=w['inter_t'],
+                           is_cold_start_user=False, is_cold_start_item=False)
+
+
+def product_net(z, case, sd_prefix, device='cuda'):
+    """Build sibrar_amd.SingleBranchNet from a golden case and load the reference's state_dict into it."""
+    import sibrar_amd as S
+    cfg = S.SingleBranchNetConfig.from_dict({'shared_common_dim': case['shared_common_dim'], 'user': dict(case['user']),
+                                             'item': dict(case['item'])})
+    orders = {k: case[k2] for k, k2 in [('user_train', 'user_train_order'), ('user_eval', 'user_eval_order'),
+                                        ('item_train', 'item_train_order'), ('item_eval', 'item_eval_order')] if k2 in case}
+    net = S.SingleBranchNet(cfg, host_dataset(world(z)), modality_orders=orders)
+    missing = net.load_state_dict(state_dict(z, sd_prefix), strict=True)
+    return net.to(device)

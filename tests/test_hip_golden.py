@@ -1,0 +1,241 @@
+"""GPU: the HIP engine behind the reference's plugin surface against (a) the golden vectors captured from the real
+reference and (b) the CPU oracle on the same inputs. Tolerance: fp32 logits / losses within 1e-4 relative (north star);
+gradients within 1e-4 of the gradient scale (see golden_util.close); integer work exact."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import (MANIFEST, load, sub, state_dict, world, ref_tables, close, gscale, bn_shadowed_biases, host_dataset,
+                         product_net, U, I)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = dict(rtol=1e-4, atol=1e-5)
+
+
+def _grads_close(module_or_params, golden, prefix=''):
+    gs = golden
+    sc = gscale(gs.values())
+    named = dict(module_or_params.named_parameters()) if hasattr(module_or_params, 'named_parameters') else module_or_params
+    for k, g in gs.items():
+        p = named[k]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(got.detach().cpu(), g, what=f'grad {k}', rtol=2e-4, atol=1e-5, scale=sc, norm_rtol=1e-4)
+
+
+@pytest.mark.parametrize('case', MANIFEST['g1_polylinear']['cases'], ids=lambda c: c['name'])
+def test_g1_polylinear(case):
+    import sibrar_amd as S
+    z = load('g1_polylinear')
+    n = case['name']
+    pl = S.PolyLinear(case['layer_config'], activation_fn=case['act'], output_fn=case['out_act'],
+                      apply_batch_norm_every=case['bn_every'])
+    pl.load_state_dict(state_dict(z, f'{n}/sd0/'), strict=True)
+    pl.to(DEV).train()
+    for s in range(3):
+        x = torch.from_numpy(z[f'{n}/x{s}']).to(DEV).requires_grad_(True)
+        y = pl(x)
+        close(y.detach().cpu(), z[f'{n}/y{s}'], what=f'y{s}', **TOL)
+        pl.zero_grad()
+        (y * torch.from_numpy(z[f'{n}/r{s}']).to(DEV)).sum().backward()
+        gs = sub(z, f'{n}/g{s}/')
+        close(x.grad.cpu(), z[f'{n}/gx{s}'], what=f'gx{s}', rtol=2e-4, atol=1e-5, scale=gscale(gs.values()), norm_rtol=1e-4)
+        _grads_close(pl, gs)
+    for k, v in sub(z, f'{n}/sd3/').items():
+        close(pl.state_dict()[k].cpu(), v, what=f'sd3/{k}', **TOL)
+    pl.eval()
+    with torch.no_grad():
+        ye = pl(torch.from_numpy(z[f'{n}/xe']).to(DEV))
+    close(ye.cpu(), z[f'{n}/ye'], what='ye', **TOL)
+
+
+def _g2_feature(w, source):
+    import sibrar_amd as S
+    ds = host_dataset(w)
+    if source == 'item_interactions':
+        return S.HostFeature('interactions', 'csr', w['inter_t'])
+    if source == 'gender':
+        return ds.user_features['gender']
+    return ds.item_features[source]
+
+
+@pytest.mark.parametrize('case', MANIFEST['g2_feature_embedding']['cases'], ids=lambda c: c['name'])
+def test_g2_feature_embedding(case):
+    import sibrar_amd as S
+    z = load('g2_feature_embedding')
+    n = case['name']
+    fe = S.FeatureEmbedding(_g2_feature(world(z), case['source']), embedding_dim=case['embedding_dim'],
+                            pre_embedding_layers=case['hidden'], activation_fn=case['act'])
+    fe.load_state_dict(state_dict(z, f'{n}/sd/'), strict=True)
+    fe.to(DEV).train()
+    idx = torch.from_numpy(z[f'{n}/idx']).to(DEV)
+    y = fe(idx)
+    y = y.reshape(z[f'{n}/y'].shape)
+    close(y.detach().cpu(), z[f'{n}/y'], what='y', **TOL)
+    (y * torch.from_numpy(z[f'{n}/r']).to(DEV)).sum().backward()
+    _grads_close(fe, sub(z, f'{n}/g/'))
+
+
+@pytest.mark.parametrize('case', MANIFEST['g3_entity']['cases'], ids=lambda c: c['name'])
+def test_g3_entity(case):
+    import sibrar_amd as S
+    z = load('g3_entity')
+    n = case['name']
+    w = world(z)
+    ds = host_dataset(w)
+    feats = dict(ds.item_features)
+    feats['interactions'] = S.HostFeature('interactions', 'csr', w['inter_t'])
+    cfg = S.SingleBranchNetEntityConfig.from_dict(dict(case['cfg']))
+    order = case['train_order']
+    if case.get('central_others_order'):
+        order = [case['cfg']['central_modality']] + case['central_others_order']
+    ent = S.SingleBranchNetEntity('item', feats, cfg, 8, True, train_modality_order=order,
+                                  eval_modality_order=case['eval_order'])
+    ent.load_state_dict(state_dict(z, f'{n}/sd0/'), strict=True)
+    ent.to(DEV).train()
+    idx = torch.from_numpy(z[f'{n}/idx']).to(DEV)
+    # (1) own draw: same stream as the reference's first call
+    pos, used_order = ent._sample_modalities(tuple(idx.shape))
+    assert (ent.modality_names(pos, used_order).reshape(z[f'{n}/mods'].shape) == z[f'{n}/mods']).all()
+    # (2) replay the recorded decision
+    y = ent(idx, modalities=z[f'{n}/mods'])
+    close(y.detach().cpu(), z[f'{n}/y'], what='y', **TOL)
+    reg = ent.get_and_reset_other_loss()['reg_loss']
+    close(reg.detach().cpu().reshape(-1), z[f'{n}/reg_loss'].reshape(-1), what='reg', **TOL)
+    ((y * torch.from_numpy(z[f'{n}/r']).to(DEV)).sum() + reg.sum()).backward()
+    _grads_close(ent, sub(z, f'{n}/g/'))
+    for k, v in sub(z, f'{n}/sd1/').items():
+        close(ent.state_dict()[k].cpu(), v, what=f'sd1/{k}', **TOL)
+    ent.eval()
+    with torch.no_grad():
+        ye = ent(torch.arange(I, device=DEV))
+    close(ye.cpu(), z[f'{n}/y_eval'], what='y_eval', **TOL)
+
+
+_LOSS = {
+    'bce': ('bce', 'mean', 'uniform_recbole'), 'bpr': ('bpr', 'mean', 'uniform_recbole'), 'bpr_sum': ('bpr', 'sum', 'uniform_recbole'),
+    'ssm_uniform': ('sampled_softmax', 'mean', 'uniform'), 'ssm_recbole': ('sampled_softmax', 'sum', 'uniform_recbole'),
+}
+
+
+def _loss(name):
+    import sibrar_amd as S
+    kind, agg, strat = _LOSS[name]
+    return S.RecommenderSystemLossesEnum[kind].value(n_items=I, aggregator=agg, train_neg_strategy=strat, neg_train=3)
+
+
+@pytest.mark.parametrize('case', MANIFEST['g4_full_net']['cases'], ids=lambda c: c['name'])
+def test_g4_full_net(case):
+    z = load('g4_full_net')
+    n = case['name']
+    net = product_net(z, case, f'{n}/sd0/')
+    net.train()
+    u, i, labels = (torch.from_numpy(z[f'{n}/{k}']).to(DEV) for k in ('u', 'i', 'labels'))
+    um = z[f'{n}/user_mods'] if f'{n}/user_mods' in z.files else None
+    logits = net(u, i, user_modalities=um, item_modalities=z[f'{n}/item_mods'])
+    assert logits.dtype == torch.float32
+    close(logits.detach().cpu(), z[f'{n}/logits'], what='logits', **TOL)
+    loss = _loss(case['loss']).compute_loss(logits, labels)
+    assert str(loss.dtype) == case['rec_loss_dtype']
+    close(loss.detach().cpu(), z[f'{n}/rec_loss'], what='rec_loss', **TOL)
+    reg = net.get_and_reset_other_loss()
+    close(reg['reg_loss'].detach().cpu(), z[f'{n}/reg_loss'], what='reg_loss', **TOL)
+    (loss + reg['reg_loss']).backward()
+    _grads_close(net, sub(z, f'{n}/g/'))
+    for k, v in sub(z, f'{n}/sd1/').items():
+        close(net.state_dict()[k].cpu(), v, what=f'sd1/{k}', **TOL)
+
+
+@pytest.mark.parametrize('case', MANIFEST['g5_infonce']['cases'], ids=lambda c: c['name'])
+def test_g5_infonce(case):
+    import sibrar_amd as S
+    z = load('g5_infonce')
+    n = case['name']
+    a = torch.from_numpy(z[f'{n}/a']).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(z[f'{n}/b']).to(DEV).requires_grad_(True)
+    loss = S.InfoNCE(case['tau'], case['reduction'])(a, b)
+    close(loss.detach().cpu(), z[f'{n}/loss'], what='loss', **TOL)
+    loss.backward()
+    close(a.grad.cpu(), z[f'{n}/ga'], what='ga', rtol=2e-4, atol=1e-5, norm_rtol=1e-4)
+    close(b.grad.cpu(), z[f'{n}/gb'], what='gb', rtol=2e-4, atol=1e-5, norm_rtol=1e-4)
+
+
+@pytest.mark.parametrize('case', MANIFEST['g8_optim']['cases'], ids=lambda c: c['name'])
+def test_g8_optimizer_trajectories(case):
+    """Three full training steps (forward, loss, backward, fused dense optimizer) replaying the reference's batches and
+    modality decisions; every parameter must end where the reference's ended (BN-shadowed biases excluded, see
+    golden_util.bn_shadowed_biases)."""
+    import sibrar_amd as S
+    z = load('g8_optim')
+    n = case['name']
+    net = product_net(z, case, f'{n}/sd0/')
+    net.train()
+    opt = S.FusedOptimizer(net, case['optimizer'], lr=case['lr'], weight_decay=case['wd'])
+    loss_fn = S.RecBayesianPersonalizedRankingLoss(n_items=I, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+    for s in range(3):
+        u, i, labels = (torch.from_numpy(z[f'{n}/{k}{s}']).to(DEV) for k in ('u', 'i', 'labels'))
+        um = z[f'{n}/user_mods{s}'] if f'{n}/user_mods{s}' in z.files else None
+        logits = net(u, i, user_modalities=um, item_modalities=z[f'{n}/item_mods{s}'])
+        loss = loss_fn.compute_loss(logits, labels)
+        reg = net.get_and_reset_other_loss()
+        close(loss.detach().cpu(), z[f'{n}/loss{s}'], what=f'loss{s}', rtol=2e-4, atol=1e-5)
+        (loss + reg['reg_loss']).backward()
+        opt.step()
+        opt.zero_grad()
+    final = sub(z, f'{n}/sd3/')
+    skip = bn_shadowed_biases(final.keys())
+    sd = net.state_dict()
+    for k, v in final.items():
+        if k not in skip:
+            close(sd[k].cpu(), v, what=f'sd3/{k}', rtol=2e-4, atol=2e-5, norm_rtol=1e-4)
+
+
+def test_g9_eval_fp32_path():
+    """Item representations, all-pairs scores, CSR mask, exact top-k and the ranking metrics against the reference's."""
+    import sibrar_amd as S
+    z = load('g9_eval')
+    case = MANIFEST['g9_eval']
+    net = product_net(z, case, 'sd/')
+    net.eval()
+    w = world(z)
+    with torch.no_grad():
+        i_repr = net.get_item_representations(torch.arange(I, device=DEV))
+        u_idx = torch.arange(U, device=DEV)
+        u_repr = net.get_user_representations(u_idx)
+        close(i_repr.cpu(), z['i_repr'], what='i_repr', **TOL)
+        close(u_repr.cpu(), z['u_repr'], what='u_repr', **TOL)
+        out = net.combine_user_item_representations(u_repr, i_repr)
+        indptr = torch.from_numpy(w['inter'].indptr.astype(np.int64)).to(DEV)
+        indices = torch.from_numpy(w['inter'].indices.astype(np.int32)).to(DEV)
+        S.ops.mask_scores_(out, u_idx, indptr, indices)
+        ref = torch.from_numpy(z['scores'])
+        assert (torch.isinf(out.cpu()) == torch.isinf(ref)).all()
+        fin = ~torch.isinf(ref)
+        close(out.cpu()[fin], ref[fin], what='scores', **TOL)
+        val, idx = S.ops.topk_rows(out, 20)
+    # top-k values equal the reference's (ranks may differ only among exact ties)
+    close(torch.nan_to_num(val.cpu(), neginf=-1e30), np.nan_to_num(z['topk_val'], neginf=-1e30), what='topk_val', **TOL)
+    # exactness of the selection itself on the engine's own scores
+    tv, ti = torch.topk(out, 20, sorted=True)
+    assert torch.equal(val, tv)
+    labels = z['labels']
+    import scipy.sparse as sp
+    lab = sp.csr_matrix(labels)
+    m = S.ops.rank_metrics(idx, u_idx, torch.from_numpy(lab.indptr.astype(np.int64)).to(DEV),
+                           torch.from_numpy(lab.indices.astype(np.int32)).to(DEV), [1, 10, 20])
+    for qi, k in enumerate([1, 10, 20]):
+        close(m[0, qi].cpu(), z[f'ndcg@{k}'], what=f'ndcg@{k}', rtol=1e-5, atol=1e-6)
+        close(m[1, qi].cpu(), z[f'recall@{k}'], what=f'recall@{k}', rtol=1e-5, atol=1e-6)
+        close(m[2, qi].cpu(), z[f'precision@{k}'], what=f'precision@{k}', rtol=1e-5, atol=1e-6)
+
+
+def test_g11_sgd_baseline():
+    import sibrar_amd as S
+    z = load('g11_sgd_baseline')
+    m = S.SGDBaseline(U, I)
+    m.load_state_dict(state_dict(z, 'sd/'))
+    m.to(DEV)
+    u, i = torch.from_numpy(z['u']).to(DEV), torch.from_numpy(z['i']).to(DEV)
+    close(m.predict(u, i).cpu(), z['logits'], what='logits', **TOL)
+    m.train()
+    close(m(u, i).detach().cpu(), z['logits'], what='logits(train)', **TOL)

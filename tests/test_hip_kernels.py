@@ -1,0 +1,320 @@
+"""GPU: kernel-level parity of the C-ABI entry points (called through the ctypes binding) against fp64/fp32 torch-CPU
+arithmetic and the oracle, at small odd sizes (edge cases: ragged tiles, empty inputs, gathers, ties) and at
+BASELINE-sized shapes through size-independent properties."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def S():
+    import sibrar_amd
+    return sibrar_amd
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 7, 3), (33, 65, 31), (128, 64, 32), (257, 130, 100), (300, 64, 768), (1000, 200, 65)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_gemm_nt(M, N, K, act):
+    ops = S().ops
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    y = ops.linear_nt(x.to(DEV), w.to(DEV), b.to(DEV), act)
+    pre = x.double() @ w.double().t() + b.double()
+    ref = {0: pre, 1: torch.relu(pre), 2: torch.tanh(pre)}[act]
+    # an fp32 dot product of K terms carries an absolute error ~ eps * sum|a_k b_k|, whatever the summation order; the
+    # tolerance is therefore relative to the pre-activation scale (the activation has slope <= 1)
+    close(y.cpu(), ref, rtol=1e-4, atol=1e-5, what='nt', norm_rtol=2e-6, scale=float(pre.abs().max()))
+
+
+def test_gemm_nt_gather_scatter_unaligned():
+    ops = S().ops
+    table = _rand(50, 18, seed=4)                      # K = 18: not a multiple of 4 -> scalar load path
+    w, b = _rand(8, 18, seed=5), _rand(8, seed=6)
+    rows = torch.tensor([3, 3, 49, 0, 17, 21, 8], dtype=torch.int32)
+    slots = torch.tensor([6, 0, 2, 9, 4, 1, 7], dtype=torch.int32)
+    out = torch.full((10, 8), 7.0, device=DEV)
+    ops.linear_nt(table.to(DEV), w.to(DEV), b.to(DEV), 1, a_idx=rows.to(DEV), out=out, c_idx=slots.to(DEV), n_rows=7)
+    ref = torch.full((10, 8), 7.0, dtype=torch.float64)
+    ref[slots.long()] = torch.relu(table[rows.long()].double() @ w.double().t() + b.double())
+    close(out.cpu(), ref, rtol=1e-4, atol=1e-5, what='gather/scatter')
+
+
+@pytest.mark.parametrize('M,N,K', [(3, 5, 7), (70, 33, 129), (513, 64, 64), (100, 768, 64)])
+def test_gemm_nn_and_tn(M, N, K):
+    ops = S().ops
+    dz, w = _rand(M, K, seed=7), _rand(K, N, seed=8)
+    close(ops.matmul_nn(dz.to(DEV), w.to(DEV)).cpu(), dz.double() @ w.double(), rtol=1e-4, atol=1e-5, what='nn', norm_rtol=1e-6)
+    x = _rand(M, N, seed=9)
+    got = ops.matmul_tn(dz.to(DEV), x.to(DEV))          # [K, N] = dz^T x over M rows
+    close(got.cpu(), dz.double().t() @ x.double(), rtol=1e-4, atol=1e-5, what='tn', norm_rtol=1e-5)
+
+
+def test_gemm_tn_large_reduction_with_gather():
+    ops = S().ops
+    R, C, F = 20000, 64, 96
+    dz, table = _rand(R, C, seed=10), _rand(500, F, seed=11)
+    rows = torch.randint(0, 500, (R,), generator=torch.Generator().manual_seed(12), dtype=torch.int32)
+    got = ops.matmul_tn(dz.to(DEV), table.to(DEV), b_idx=rows.to(DEV), n_rows=R)
+    ref = dz.double().t() @ table[rows.long()].double()
+    close(got.cpu(), ref, rtol=1e-4, atol=1e-4, what='tn split-k', norm_rtol=1e-5)
+
+
+def test_gemm_empty():
+    ops = S().ops
+    y = ops.linear_nt(torch.empty(0, 8, device=DEV), torch.randn(4, 8, device=DEV), None, 0)
+    assert y.shape == (0, 4)
+    g = ops.matmul_tn(torch.empty(0, 4, device=DEV), torch.empty(0, 8, device=DEV))
+    assert torch.count_nonzero(g) == 0
+
+
+@pytest.mark.parametrize('n,D', [(2, 3), (11, 7), (1000, 64), (4097, 130)])
+@pytest.mark.parametrize('act', [0, 1, 3, 4])
+def test_batchnorm_train_and_eval(n, D, act):
+    ops = S().ops
+    x = _rand(n, D, seed=20) * 2 + 0.5
+    w, b = torch.rand(D) + 0.5, _rand(D, seed=21)
+    r = _rand(n, D, seed=22)
+    names = {0: None, 1: 'relu', 3: 'sigmoid', 4: 'selu'}
+    from oracle import model_ref
+    sd = {'weight': w.clone().requires_grad_(True), 'bias': b.clone().requires_grad_(True),
+          'running_mean': torch.zeros(D), 'running_var': torch.ones(D), 'num_batches_tracked': torch.zeros((), dtype=torch.long)}
+    xr = x.clone().requires_grad_(True)
+    yr = model_ref._act(names[act], model_ref.batch_norm(xr, sd, '', True))
+    (yr * r).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rm, rv, nb = torch.zeros(D, device=DEV), torch.ones(D, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    y = ops.BatchNormActFn.apply(xd, wd, bd, rm, rv, nb, act)
+    close(y.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-5, what='y')
+    (y * r.to(DEV)).sum().backward()
+    sc = float(xr.grad.abs().max())
+    close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5, what='dx', norm_rtol=1e-4, scale=sc)
+    close(wd.grad.cpu(), sd['weight'].grad, rtol=1e-4, atol=1e-4, what='dw', norm_rtol=1e-4)
+    close(bd.grad.cpu(), sd['bias'].grad, rtol=1e-4, atol=1e-4, what='db', norm_rtol=1e-4)
+    close(rm.cpu(), sd['running_mean'], rtol=1e-4, atol=1e-6, what='running_mean')
+    close(rv.cpu(), sd['running_var'], rtol=1e-4, atol=1e-6, what='running_var')
+    assert int(nb) == 1
+    ye = ops.batch_norm_eval(x.to(DEV), w.to(DEV), b.to(DEV), rm, rv, act)
+    yre = model_ref._act(names[act], model_ref.batch_norm(x, {k: v.detach() for k, v in sd.items()}, '', False))
+    close(ye.cpu(), yre, rtol=1e-4, atol=1e-5, what='eval')
+
+
+def test_l2norm_dropout_aggregate():
+    ops = S().ops
+    x = _rand(37, 24, seed=30)
+    x[3] = 0                                           # zero row: clamped by eps
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.L2NormalizeFn.apply(xd)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.normalize(xr, p=2, dim=-1)
+    close(y.detach().cpu(), yr.detach(), what='normalize')
+    r = _rand(37, 24, seed=31)
+    (y * r.to(DEV)).sum().backward()
+    (yr * r).sum().backward()
+    mask = torch.ones(37, dtype=torch.bool)
+    mask[3] = False
+    close(xd.grad.cpu()[mask], xr.grad[mask], rtol=1e-4, atol=1e-5, what='normalize grad', norm_rtol=1e-5)
+    # dropout: keep-rate, scaling, backward uses the same mask
+    big = torch.ones(1000, 64, device=DEV, requires_grad=True)
+    d = ops.DropoutFn.apply(big, 0.2, 1234)
+    kept = (d > 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01 and torch.allclose(d[d > 0], torch.tensor(1.25, device=DEV))
+    d.sum().backward()
+    assert torch.equal(big.grad > 0, d > 0)
+    assert not torch.equal(ops.DropoutFn.apply(big, 0.2, 1235) > 0, d > 0)
+    # aggregate
+    e = _rand(13, 2, 9, seed=32)
+    for mode, fn in [(0, lambda t: t.mean(1)), (1, lambda t: t.max(1).values)]:
+        ed = e.to(DEV).requires_grad_(True)
+        er = e.clone().requires_grad_(True)
+        out = ops.AggregateFn.apply(ed, mode)
+        close(out.detach().cpu(), fn(er).detach(), what='aggregate')
+        g = _rand(13, 9, seed=33)
+        (out * g.to(DEV)).sum().backward()
+        (fn(er) * g).sum().backward()
+        close(ed.grad.cpu(), er.grad, what='aggregate grad')
+
+
+@pytest.mark.parametrize('kind', ['bce', 'bpr', 'sampled_softmax'])
+@pytest.mark.parametrize('agg', ['mean', 'sum'])
+@pytest.mark.parametrize('B,N', [(1, 2), (6, 4), (300, 11), (8192, 11)])
+def test_rec_losses_vs_oracle(kind, agg, B, N):
+    import sibrar_amd as Sm
+    from oracle import losses_ref
+    logits = _rand(B, N, seed=40) * 3
+    labels = torch.zeros(B, N, dtype=torch.float64)
+    labels[:, 0] = 1
+    for strat in (['uniform', 'uniform_recbole'] if kind == 'sampled_softmax' else ['uniform_recbole']):
+        lr = logits.clone().requires_grad_(True)
+        ref = losses_ref.RefRecLoss(kind, n_items=5000, aggregator=agg, train_neg_strategy=strat, neg_train=N - 1).compute_loss(lr, labels)
+        ref.backward()
+        ld = logits.to(DEV).requires_grad_(True)
+        got = Sm.RecommenderSystemLossesEnum[kind].value(n_items=5000, aggregator=agg, train_neg_strategy=strat,
+                                                         neg_train=N - 1).compute_loss(ld, labels.to(DEV))
+        assert got.dtype == ref.dtype
+        close(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6, what='loss')
+        got.backward()
+        close(ld.grad.cpu(), lr.grad, rtol=1e-4, atol=1e-7, what='dlogits', norm_rtol=1e-5)
+
+
+@pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8)])
+def test_infonce_vs_oracle(G, N, D):
+    import sibrar_amd as Sm
+    from oracle import model_ref
+    a, b = _rand(G, N, D, seed=50) * 0.5, _rand(G, N, D, seed=51) * 0.5
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = model_ref.info_nce(ar, br, 0.3)
+    ref.backward()
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    got = Sm.InfoNCE(0.3)(ad, bd)
+    close(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6, what='infonce')
+    got.backward()
+    close(ad.grad.cpu(), ar.grad, rtol=2e-4, atol=1e-6, what='da', norm_rtol=1e-4)
+    close(bd.grad.cpu(), br.grad, rtol=2e-4, atol=1e-6, what='db', norm_rtol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['adamw', 'adam', 'adagrad'])
+def test_fused_optimizer_vs_update_rules(name):
+    ops = S().ops
+    from oracle import train_ref
+    n = 10007
+    p0, g = _rand(n, seed=60), _rand(3, n, seed=61)
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for s in range(3):
+        if name == 'adagrad':
+            p, m = train_ref.adagrad_update(p, g[s], m, s + 1, 1e-2, 1e-2)
+            ops.adagrad_step(pd, g[s].to(DEV), md, 1e-2, 1e-10, 1e-2)
+        else:
+            fn = train_ref.adamw_update if name == 'adamw' else train_ref.adam_update
+            p, m, v = fn(p, g[s], m, v, s + 1, 1e-2, 1e-2)
+            ops.adam_step(0 if name == 'adamw' else 1, pd, g[s].to(DEV), md, vd, 1e-2, 0.9, 0.999, 1e-8, 1e-2, s + 1)
+    close(pd.cpu(), p, rtol=1e-5, atol=1e-6, what=name)
+
+
+def test_topk_exact_ties_and_mask():
+    ops = S().ops
+    g = torch.Generator().manual_seed(70)
+    sc = torch.randn(64, 3299, generator=g)
+    sc[:, ::7] = sc[:, 1::7]                           # many exact ties
+    sc[5] = -float('inf')
+    sc[5, :3] = torch.tensor([1., 1., 2.])             # fewer finite values than k
+    d = sc.to(DEV)
+    for k in (1, 10, 20, 100, 256):
+        val, idx = ops.topk_rows(d, k)
+        tv, _ = torch.topk(sc, k, sorted=True)
+        assert torch.equal(val.cpu(), tv)
+        # indices: point at the returned values, distinct, ties broken towards the lower index
+        assert torch.equal(torch.gather(sc, 1, idx.cpu().long()), val.cpu())
+        srt = idx.cpu().long()
+        assert all(len(set(r.tolist())) == k for r in srt)
+        same = val[:, 1:].cpu() == val[:, :-1].cpu()
+        assert (srt[:, 1:][same] > srt[:, :-1][same]).all()
+    # CSR mask
+    import scipy.sparse as sp
+    m = sp.random(64, 3299, density=0.02, format='csr', random_state=1)
+    out = torch.randn(64, 3299, device=DEV)
+    u = torch.arange(63, -1, -1, device=DEV)           # reversed user order: row b uses CSR row u[b]
+    before = out.clone()
+    ops.mask_scores_(out, u, torch.from_numpy(m.indptr.astype(np.int64)).to(DEV), torch.from_numpy(m.indices.astype(np.int32)).to(DEV))
+    dense = torch.from_numpy(m.toarray() != 0)[u.cpu()]
+    assert torch.isinf(out.cpu()[dense]).all() and torch.equal(out.cpu()[~dense], before.cpu()[~dense])
+
+
+@pytest.mark.parametrize('Bu,I,D,k', [(5, 70, 64, 3), (300, 1000, 128, 20), (257, 3299, 64, 10), (1000, 5000, 256, 20)])
+def test_fused_f16_scorer_matches_unfused(Bu, I, D, k):
+    """fp16-MFMA score + mask + top-k == (fp32 matmul of the same fp16-rounded inputs -> mask -> exact top-k)."""
+    ops = S().ops
+    import scipy.sparse as sp
+    u = (_rand(Bu, D, seed=80) / 4).half()
+    it = (_rand(I, D, seed=81) / 4).half()
+    m = sp.random(Bu, I, density=0.03, format='csr', random_state=2)
+    m.sort_indices()
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(DEV)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(DEV)
+    uidx = torch.arange(Bu, device=DEV)
+    val, idx = ops.score_topk_f16(u.to(DEV), it.to(DEV), k, uidx, indptr, indices)
+    ref = (u.double() @ it.double().t())
+    ref[torch.from_numpy(m.toarray() != 0)] = -float('inf')
+    tv, ti = torch.topk(ref, k, sorted=True)
+    close(val.cpu(), tv, rtol=1e-5, atol=1e-5, what='fused values')
+    # the selected items' exact scores equal the returned values and none of them is excluded
+    got = torch.gather(ref, 1, idx.cpu().long())
+    close(got, tv, rtol=1e-5, atol=1e-5, what='fused indices')
+    assert not torch.isinf(got).any()
+
+
+def test_fused_f16_scorer_sorted_catalogue_and_item_offset():
+    """Adversarial order: scores increase with the item index, so every tile overflows the candidate buffers."""
+    ops = S().ops
+    Bu, I, D, k = 64, 2000, 64, 20
+    it = torch.zeros(I, D)
+    it[:, 0] = torch.linspace(-1, 1, I)
+    u = torch.zeros(Bu, D)
+    u[:, 0] = 1.0
+    val, idx = ops.score_topk_f16(u.half().to(DEV), it.half().to(DEV), k, item_offset=1000)
+    ref = (u.half().double() @ it.half().double().t())
+    tv, ti = torch.topk(ref, k, sorted=True)
+    close(val.cpu(), tv, rtol=1e-6, atol=1e-6, what='values')
+    assert (idx.cpu() >= 1000).all()
+    close(torch.gather(ref, 1, idx.cpu().long() - 1000), tv, rtol=1e-6, atol=1e-6, what='indices')
+
+
+def test_rank_metrics_vs_oracle():
+    ops = S().ops
+    from oracle import eval_ref
+    import scipy.sparse as sp
+    Bu, I = 200, 500
+    g = torch.Generator().manual_seed(90)
+    scores = torch.randn(Bu, I, generator=g)
+    lab = sp.random(Bu, I, density=0.02, format='csr', random_state=3)
+    lab.data[:] = 1
+    lab.sort_indices()
+    lab = sp.csr_matrix(lab)
+    lab[7] = 0                                         # a user without positives
+    lab.eliminate_zeros()
+    y = torch.from_numpy(lab.toarray().astype(np.float32))
+    val, idx = ops.topk_rows(scores.to(DEV), 20)
+    m = ops.rank_metrics(idx, None, torch.from_numpy(lab.indptr.astype(np.int64)).to(DEV),
+                         torch.from_numpy(lab.indices.astype(np.int32)).to(DEV), [1, 10, 20])
+    for qi, k in enumerate([1, 10, 20]):
+        ii = idx.cpu().long()[:, :k]
+        close(m[0, qi].cpu(), eval_ref.ndcg_at_k(y, ii), rtol=1e-5, atol=1e-6, what=f'ndcg@{k}')
+        close(m[1, qi].cpu(), eval_ref.recall_at_k(y, ii), rtol=1e-5, atol=1e-6, what=f'recall@{k}')
+        close(m[2, qi].cpu(), eval_ref.precision_at_k(y, ii), rtol=1e-5, atol=1e-6, what=f'precision@{k}')
+
+
+def test_full_size_properties_c2_shapes():
+    """BASELINE config-2-sized shapes (U 100k, I 50k, F 768, D 128) through size-independent properties:
+    linearity of the projector GEMM, and fused-scorer == unfused scorer on a user sample."""
+    ops = S().ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    I, F, C = 50000, 768, 128
+    X = torch.randn(I, F, device=DEV, generator=g)
+    W1, W2 = torch.randn(C, F, device=DEV, generator=g), torch.randn(C, F, device=DEV, generator=g)
+    rows = torch.randint(0, I, (90112,), device=DEV, generator=g, dtype=torch.int32)
+    y1, y2 = ops.linear_nt(X, W1, None, 0, a_idx=rows), ops.linear_nt(X, W2, None, 0, a_idx=rows)
+    y12 = ops.linear_nt(X, W1 + W2, None, 0, a_idx=rows)
+    err = (y1 + y2 - y12).abs().max().item()
+    assert err < 2e-3 * y12.abs().max().item() + 1e-3, err
+    ref = X[rows.long()[:64]].double() @ W1.double().t()
+    close(y1[:64].cpu(), ref.cpu(), rtol=1e-4, atol=1e-3, what='sampled rows', norm_rtol=1e-5)
+    # scoring
+    U_ = torch.randn(4096, C, device=DEV, generator=g) / 8
+    It = torch.randn(I, C, device=DEV, generator=g) / 8
+    u16, i16 = ops.cast_f16(U_), ops.cast_f16(It)
+    val, idx = ops.score_topk_f16(u16, i16, 20)
+    sc = ops.linear_nt(u16.float(), i16.float())
+    tv, ti = ops.topk_rows(sc, 20)
+    close(val.cpu(), tv.cpu(), rtol=1e-4, atol=1e-5, what='fused vs unfused values')
+    assert (idx == ti).float().mean().item() > 0.999
