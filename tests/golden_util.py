@@ -128,11 +128,19 @@ def host_dataset(w):
                            is_cold_start_user=False, is_cold_start_item=False)
 
 
+def side_cfg(d):
+    """Golden manifests do not record ``preference_hidden_layers`` (unused by the model, required by the config class)."""
+    d = dict(d)
+    if 'features' in d:
+        d.setdefault('preference_hidden_layers', [])
+    return d
+
+
 def product_net(z, case, sd_prefix, device='cuda'):
     """Build sibrar_amd.SingleBranchNet from a golden case and load the reference's state_dict into it."""
     import sibrar_amd as S
-    cfg = S.SingleBranchNetConfig.from_dict({'shared_common_dim': case['shared_common_dim'], 'user': dict(case['user']),
-                                             'item': dict(case['item'])})
+    cfg = S.SingleBranchNetConfig.from_dict({'shared_common_dim': case['shared_common_dim'], 'user': side_cfg(case['user']),
+                                             'item': side_cfg(case['item'])})
     orders = {k: case[k2] for k, k2 in [('user_train', 'user_train_order'), ('user_eval', 'user_eval_order'),
                                         ('item_train', 'item_train_order'), ('item_eval', 'item_eval_order')] if k2 in case}
     net = S.SingleBranchNet(cfg, host_dataset(world(z)), modality_orders=orders)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from golden_util import (MANIFEST, load, sub, state_dict, world, ref_tables, close, gscale, bn_shadowed_biases, host_dataset,
-                         product_net, U, I)
+                         product_net, side_cfg, U, I)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -85,7 +85,7 @@ def test_g3_entity(case):
     ds = host_dataset(w)
     feats = dict(ds.item_features)
     feats['interactions'] = S.HostFeature('interactions', 'csr', w['inter_t'])
-    cfg = S.SingleBranchNetEntityConfig.from_dict(dict(case['cfg']))
+    cfg = S.SingleBranchNetEntityConfig.from_dict(side_cfg(case['cfg']))
     order = case['train_order']
     if case.get('central_others_order'):
         order = [case['cfg']['central_modality']] + case['central_others_order']
