@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — training interactions/s (+ full-catalogue scores/s) of the HIP SingleBranchNet engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1], "c2"): synthetic 100k users x 50k items, ~5M interactions, one 768-d dense item
+modality + item-id embedding, common/shared dim 128, hidden [128], sampled-softmax loss, 10 negatives, AdamW(1e-3, 1e-6);
+user side = embedding lookup. A "step" is one full training batch through the reference's hot loop
+(train/trainer.py:204-223): draw the batch (shuffled epoch order + bit-exact negative sampling), draw the modalities,
+forward, sampled-softmax loss, backward, dense AdamW over every parameter. Features, tables, parameters and optimizer
+state are resident in HBM before the timed region; only the index tensors of each batch cross PCIe.
+
+Prints ONE JSON line (rank 0). ``value`` = interactions (positive rows) per second over all ranks, weak scaling (per-GPU
+batch fixed). Extra objects: ``roofline`` (dominant training kernel, HIP-event timed live), ``scoring`` (fused fp16
+score+mask+top-k over the full catalogue: scores/s and its own roofline), ``cpu_baseline`` (the CPU oracle restatement of
+the same step timed on this box's host cores, rank 0, N=1 only), ``b256`` (the same step at the reference's default batch).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_MFMA_F16 = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_HBM = 8000.0         # GB/s
+
+C2 = dict(n_users=100_000, n_items=50_000, nnz=5_000_000, feat_dim=768, emb_dim=128, n_neg=10)
+
+
+def model_config(emb_dim):
+    return {'shared_common_dim': emb_dim, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+            'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                     'single_branch_hidden_layers': [emb_dim], 'preference_hidden_layers': [], 'common_modality_dim': emb_dim}}
+
+
+def build(S, cfg, device, seed=0):
+    ds = S.SyntheticDataset(cfg['n_users'], cfg['n_items'], cfg['nnz'], item_dense={'text': cfg['feat_dim']}, seed=seed,
+                            n_negative_samples=cfg['n_neg'], negative_sampling_strategy='uniform_recbole',
+                            holdout_per_user=0)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(model_config(cfg['emb_dim'])), ds).to(device)
+    return ds, net
+
+
+class _Conf:
+    """the parts of ExperimentConfig the Trainer reads (data/config_classes.py:198-248)"""
+    def __init__(self, device):
+        self.learn = {'lr': 1e-3, 'wd': 1e-6, 'optimizer': 'adamw', 'n_epochs': 1, 'optimizing_metric': 'ndcg@10'}
+        self.run_settings = {'device': device, 'batch_verbose': False}
+        self.results_path = None
+        self.eval = None
+        self.train_eval = None
+
+
+def run_steps(S, trainer, loader_iter, n, world):
+    for _ in range(n):
+        u, i, l = next(loader_iter)
+        trainer.train_step(u, i, l)
+
+
+def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_kernels):
+    import torch.distributed as dist
+    loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                   neg_train=ds.n_negative_samples)
+    trainer = S.Trainer(net, None, None, loss, _Conf(device))
+    net.train()
+    loader = S.NegativeSamplingDataLoader(ds, batch_size=batch * world, shuffle=True, rank=rank, world=world, device=device,
+                                          prefetch=4)
+    it = iter(loader)
+    run_steps(S, trainer, it, warmup, world)
+    S.ops.KernelTimer.reset(time_kernels)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run_steps(S, trainer, it, steps, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timings = S.ops.KernelTimer.results() if time_kernels else {}
+    S.ops.KernelTimer.reset(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, timings
+
+
+def dominant_gemm(timings, steps):
+    """-> roofline dict of the GEMM signature with the largest total time over the timed region."""
+    best = None
+    for key, ts in timings.items():
+        if key[0] != 'gemm_f32' or not ts:
+            continue
+        tot = sum(ts)
+        if best is None or tot > best[1]:
+            best = (key, tot, ts)
+    if best is None:
+        return None
+    (_, mode, M, N, K, gathered), tot, ts = best
+    avg_ms = tot / len(ts)
+    flops = 2.0 * M * N * K
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': None,
+            'kernel': f'gemm_f32_kernel mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}',
+            'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'share_of_step': round(tot / steps, 4)}
+
+
+def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
+    """Full-catalogue scoring with the fused fp16 kernel: all users x all items (item-sharded over ranks), top-k."""
+    import torch.distributed as dist
+    net.eval()
+    with torch.no_grad():
+        i_repr = net.get_item_representations(torch.arange(ds.n_items, device=device))
+        lo, hi = S.parallel.item_shard(ds.n_items, rank, world)
+        i16 = S.ops.cast_f16(i_repr[lo:hi].contiguous())
+        users = torch.arange(ds.n_users, device=device)
+        u16 = S.ops.cast_f16(net.get_user_representations(users))
+        excl = S.evaluation._csr_to_device(ds.user_sampling_matrix_train, device)
+        S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)         # warm-up
+        S.ops.KernelTimer.reset(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+            if world > 1:
+                val, idx = S.parallel.all_gather_topk(val, idx, k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / reps
+        ts = [t for key, v in S.ops.KernelTimer.results().items() if key[0] == 'score_topk_f16' for t in v]
+        S.ops.KernelTimer.reset(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    avg_ms = sum(ts) / len(ts)
+    flops = 2.0 * ds.n_users * (hi - lo) * i16.shape[1]
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {'metric': 'full-catalogue scores/s (fused fp16 score+mask+top-20)', 'value': ds.n_users * ds.n_items / dt,
+            'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
+            'sharding': f'items/{world}',
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_MFMA_F16, 4), 'traffic': None, 'kernel': 'score_topk_f16_kernel',
+                         'avg_launch_ms': round(avg_ms, 4)}}
+
+
+def cpu_baseline(S, ds, net, batch, budget_s=20.0):
+    """The CPU oracle restatement (oracle/) of the same training step on this box's host cores: same model parameters,
+    same literal per-row sampling calls as the reference, torch-CPU fp32 ops, torch.optim.AdamW."""
+    from oracle import model_ref, losses_ref, sampling_ref, train_ref
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
+    it = {'text': model_ref.table_from_feature(ds.item_features['text']),
+          'item_embedding': model_ref.RefTable('categorical', np.arange(ds.n_items), n_categories=ds.n_items)}
+    ref = model_ref.RefSingleBranchNet(sd, model_config(net.config.shared_common_dim), ut, it)
+    loss = losses_ref.RefRecLoss('sampled_softmax', n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                 neg_train=ds.n_negative_samples)
+    params = [p for k, p in sd.items() if p.requires_grad and 'running' not in k]
+    opt = train_ref.make_optimizer('adamw', params, 1e-3, 1e-6)
+    inter = ds.user_sampling_matrix
+    positives = [inter.indices[inter.indptr[u]:inter.indptr[u + 1]] for u in range(ds.n_users)]
+    coo = ds.interaction_matrix
+    rng = np.random.default_rng(0)
+    n_steps, t_total = 0, 0.0
+    while t_total < budget_s and n_steps < 50:
+        sel = rng.integers(0, coo.nnz, size=batch)
+        t0 = time.perf_counter()
+        u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
+        train_ref.train_step(ref, loss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l))
+        dt = time.perf_counter() - t0
+        if n_steps > 0 or dt > budget_s / 2:      # first step warms caches / allocators
+            t_total += dt
+        n_steps += 1
+    timed = max(n_steps - 1, 1) if t_total > 0 else 1
+    return {'value': round(batch * timed / max(t_total, 1e-9), 1), 'unit': 'interactions/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{timed} training steps of batch {batch} on the same c2 synthetic data (CPU oracle restatement, '
+                      f'torch {torch.__version__} CPU fp32, {cores} threads)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch-size', type=int, default=8192, help='per-GPU batch (positive interactions per step)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-scoring', action='store_true')
+    ap.add_argument('--no-b256', action='store_true')
+    ap.add_argument('--small', action='store_true', help='1/10-size workload (debug only; never a reportable number)')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = f'cuda:{local}'
+    torch.cuda.set_device(local)
+
+    import sibrar_amd as S
+    cfg = dict(C2)
+    if args.small:
+        cfg.update(n_users=10_000, n_items=5_000, nnz=500_000)
+    ds, net = build(S, cfg, device)
+
+    dt, timings = bench_training(S, ds, net, device, args.batch_size, args.steps, args.warmup, rank, world, time_kernels=True)
+    value = args.batch_size * world * args.steps / dt
+    out = {
+        'metric': 'training interactions/s', 'value': round(value, 1), 'unit': 'interactions/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: synthetic 100k users x 50k items, feat_dim=768, emb_dim=128, '
+                               'sampled-softmax, 10 negatives, AdamW; user = embedding lookup, item = SingleBranchNet entity '
+                               '(text 768-d + item-id embedding, hidden [128], BatchNorm)' + (' [SMALL DEBUG SIZE]' if args.small else ''),
+                   'batch_per_gpu': args.batch_size, 'global_batch': args.batch_size * world, 'n_negatives': cfg['n_neg'],
+                   'parallelism': f'dp{world}' if world > 1 else 'single'},
+    }
+    roof = dominant_gemm(timings, args.steps) if rank == 0 else None
+    if roof:
+        out['roofline'] = roof
+    if not args.no_b256:
+        dt256, _ = bench_training(S, ds, net, device, 256, max(args.steps, 30), args.warmup, rank, world, time_kernels=False)
+        out['b256'] = {'value': round(256 * world * max(args.steps, 30) / dt256, 1), 'unit': 'interactions/s',
+                       'ms_per_step': round(dt256 / max(args.steps, 30) * 1e3, 3), 'batch_per_gpu': 256}
+    if not args.no_scoring:
+        sc = bench_scoring(S, ds, net, device, rank, world)
+        sc['value'] = round(sc['value'], 1)
+        out['scoring'] = sc
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(S, ds, net, args.batch_size)
+        out['cpu_baseline']['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -56,6 +56,11 @@ int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const flo
 int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg, const int* seg_offsets,
                      const int* const* rowmaps, int* rows_out, int* err_flag, void* stream);
 
+/* out[j] = 1 iff (rows[j], cols[j]) is a stored entry of the CSR matrix (sorted column indices): the `v in positives` test of
+ * the negative-sampling collate, data/dataloader.py:184-191, for all slots of a round at once. */
+int sbr_csr_contains(const long* indptr, const int* indices, const long* rows, const long* cols, long n, unsigned char* out,
+                     void* stream);
+
 /* nn.Embedding forward — algorithms/sgd_alg.py:1331,1386: out[oi(j), :] = W[rows[j], :] */
 int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx, long n, int D,
                     void* stream);

@@ -494,3 +494,32 @@ extern "C" int sbr_bias_score_fwd(const float* user_bias, const float* item_bias
   SBR_CHECK_LAUNCH("sbr_bias_score_fwd");
   return SBR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// membership test of (row, col) pairs in a CSR matrix with sorted column indices — the `v in positives` test of the
+// negative-sampling collate (data/dataloader.py:184-191), evaluated for all still-colliding slots of a batch at once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void csr_contains_kernel(const long* __restrict__ indptr, const int* __restrict__ indices,
+                                    const long* __restrict__ rows, const long* __restrict__ cols, long n,
+                                    unsigned char* __restrict__ out) {
+  const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long r = rows[j];
+  const int c = (int)cols[j];
+  long lo = indptr[r], hi = indptr[r + 1];
+  const long end = hi;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (indices[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  out[j] = (lo < end && indices[lo] == c) ? 1 : 0;
+}
+
+extern "C" int sbr_csr_contains(const long* indptr, const int* indices, const long* rows, const long* cols, long n,
+                                unsigned char* out, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(indptr && indices && rows && cols && out, "sbr_csr_contains: null operand");
+  csr_contains_kernel<<<sbr_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(indptr, indices, rows, cols, n, out);
+  SBR_CHECK_LAUNCH("sbr_csr_contains");
+  return SBR_OK;
+}

@@ -3,22 +3,21 @@
 //   out[b, excl(u_b)] = -inf (eval.py:219-220) applied to the few values that matter,
 //   running exact top-k per user kept on chip; output sorted by (score desc, item index asc).
 //
-// Geometry: one workgroup = 8 wavefronts = 256 users; wave w owns users [32w, 32w+32) of the block for the whole kernel and
-// keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is streamed once per workgroup
-// through a double-buffered, XOR-swizzled LDS tile of 64 items; every wave multiplies its 32 users by the 64 items
-// (2 x D/16 MFMAs per tile). Each accumulator value is compared with its row's current k-th best score held in a register;
-// only the rare survivors are checked against the user's exclusion list (binary search in the CSR row) and appended to the
-// row's candidate buffer in LDS. A full buffer is compacted by its owning wave (rank by counting), which raises the row's
-// threshold. Rows are owned by exactly one wave, so no cross-wave synchronisation is needed for the top-k state.
+// Geometry: one workgroup = 4 wavefronts = 128 users (two workgroups per CU); wave w owns users [32w, 32w+32) of the block
+// for the whole kernel and keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is
+// streamed once per workgroup through a double-buffered, XOR-swizzled LDS tile of 64 items; every wave multiplies its 32
+// users by the 64 items (2 x D/16 MFMAs per tile). Each accumulator value is compared with its row's current k-th best score
+// held in a register; only the rare survivors are tested against the tile's exclusion bit mask (each lane walks the sorted
+// exclusion row of one user in step with the tiles) and appended to the row's candidate buffer in LDS. A full buffer is
+// compacted by its owning wave (rank by counting), which raises the row's threshold. Rows are owned by exactly one wave, so
+// no cross-wave synchronisation is needed for the top-k state.
 #include "common.h"
 #include <hip/hip_fp16.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define ST_ROWS 256       // users per workgroup
 #define ST_TILE 64        // items per LDS tile
-#define ST_THREADS 512
 
 __device__ __forceinline__ unsigned int st_f2key(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -29,10 +28,8 @@ __device__ __forceinline__ float st_key2f(unsigned int k) {
 }
 
 struct TopkState {
-  unsigned long long* buf;   // [ST_ROWS][cap] composite keys (score key << 32 | ~item)
-  int* cnt;                  // [ST_ROWS]
-  long* ebeg;                // [ST_ROWS] exclusion CSR row bounds of each user of the block (ebeg > eend: row is padding)
-  long* eend;                // [ST_ROWS]
+  unsigned long long* buf;   // [rows][cap] composite keys (score key << 32 | ~item)
+  int* cnt;                  // [rows]
   int cap, k;
 };
 
@@ -53,27 +50,14 @@ __device__ __forceinline__ float st_compact(const TopkState& st, int r, int lane
   return thr;
 }
 
-// slow path of one accumulator register step. Returns the (possibly raised) threshold of this lane's row.
-__device__ __noinline__ float st_insert(TopkState st, float v, bool cand, int row, int gitem, float thr,
-                                        const int* __restrict__ excl, int lane) {
-  if (cand) {      // exclusion check: binary search in the user's sorted exclusion row
-    const long ebeg = st.ebeg[row], eend = st.eend[row];
-    if (ebeg > eend) cand = false;      // padding row of the last block
-    long lo = ebeg, hi = eend;
-    while (lo < hi) {
-      const long mid = (lo + hi) >> 1;
-      if (excl[mid] < gitem) lo = mid + 1; else hi = mid;
-    }
-    if (lo < eend && excl[lo] == gitem) cand = false;
-  }
-  const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)gitem);
-  bool pending = cand;
-  while (__ballot(pending)) {
-    if (pending) {
-      const int pos = atomicAdd(&st.cnt[row], 1);
-      if (pos < st.cap) { st.buf[row * st.cap + pos] = key; pending = false; }
-    }
+// overflow path of one accumulator register step: some lanes could not append because their row's buffer is full.
+// Compacts those rows (raising their thresholds) and retries until every pending candidate is stored or beaten.
+// Returns the (possibly raised) threshold of this lane's row.
+__device__ __noinline__ float st_overflow(TopkState st, float v, bool pending, int row, unsigned long long key, float thr,
+                                          int lane) {
+  for (;;) {
     unsigned long long ov = __ballot(pending);
+    if (!ov) break;
     while (ov) {
       const int src = __ffsll((long long)ov) - 1;
       const int r = __shfl(row, src, 64);
@@ -84,16 +68,22 @@ __device__ __noinline__ float st_insert(TopkState st, float v, bool cand, int ro
       }
       ov &= ~__ballot(row == r);
     }
+    if (pending) {
+      const int pos = atomicAdd(&st.cnt[row], 1);
+      if (pos < st.cap) { st.buf[row * st.cap + pos] = key; pending = false; }
+    }
   }
   return thr;
 }
 
-template <int KS>   // KS = D / 16
-__global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
+template <int KS, int WAVES>   // KS = D / 16; WAVES x 32 users per workgroup
+__global__ __launch_bounds__(WAVES * 64, (KS >= 16 ? 1 : 2)) void score_topk_f16_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
     float* __restrict__ out_val, int* __restrict__ out_idx) {
   constexpr int D = KS * 16;
+  constexpr int ROWS = WAVES * 32;
+  constexpr int THREADS = WAVES * 64;
   constexpr int ROWB = D * 2;              // bytes per item row
   constexpr int TILEB = ST_TILE * ROWB;    // bytes per LDS tile
   constexpr int SWZ = (D / 8 >= 16) ? 15 : (D / 8 - 1);   // XOR swizzle mask over the 16-byte chunks of a row
@@ -102,54 +92,54 @@ __global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
   unsigned char* tile1 = smem + TILEB;
   TopkState st;
   st.buf = reinterpret_cast<unsigned long long*>(smem + 2 * TILEB);
-  st.ebeg = reinterpret_cast<long*>(smem + 2 * TILEB + (size_t)ST_ROWS * cap * 8);
-  st.eend = st.ebeg + ST_ROWS;
-  st.cnt = reinterpret_cast<int*>(st.eend + ST_ROWS);
+  st.cnt = reinterpret_cast<int*>(smem + 2 * TILEB + (size_t)ROWS * cap * 8);
   st.cap = cap;
   st.k = k;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const long row0 = (long)blockIdx.x * ST_ROWS;
+  const long row0 = (long)blockIdx.x * ROWS;
 
-  if (t < ST_ROWS) {
-    st.cnt[t] = 0;
-    const long ur = row0 + t;
-    long eb = 1, ee = 0;                 // padding row
-    if (ur < Bu) {
-      eb = ee = 0;
-      if (excl_indptr) {
-        const long u = u_idx ? u_idx[ur] : ur;
-        eb = excl_indptr[u];
-        ee = excl_indptr[u + 1];
-      }
-    }
-    st.ebeg[t] = eb;
-    st.eend[t] = ee;
-  }
+  if (t < ROWS) st.cnt[t] = 0;
 
   // A fragments: user row (32*wave + l31), k = 16*s + 8*half + j
   f16x8 afrag[KS];
+  const long my_row = row0 + wave * 32 + l31;            // the user row this lane loads and whose exclusion list it walks
   {
-    long ur = row0 + wave * 32 + l31;
-    if (ur >= Bu) ur = Bu - 1;
+    const long ur = my_row < Bu ? my_row : Bu - 1;
     const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
 #pragma unroll
     for (int s = 0; s < KS; ++s) afrag[s] = src[2 * s + half];
   }
-  // the rows whose accumulators this lane sees: local row (reg&3) + 8*(reg>>2) + 4*half of the wave's 32
+  // exclusion cursor of row l31 of this wave (eval/eval.py:219-220): the user's sorted CSR row is consumed in step with the
+  // item tiles; per tile a 64-bit mask of the excluded columns is kept in a register (both lane halves hold a copy).
+  long ecur = 0, eend = 0;
+  int enext = 0x7FFFFFFF;
+  const bool row_valid = my_row < Bu;
+  if (row_valid && excl_indptr) {
+    const long u = u_idx ? u_idx[my_row] : my_row;
+    long lo = excl_indptr[u];
+    eend = excl_indptr[u + 1];
+    long hi = eend;
+    while (lo < hi) {                                      // first entry >= item_offset (item-sharded catalogues)
+      const long mid = (lo + hi) >> 1;
+      if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
+    }
+    ecur = lo;
+    if (ecur < eend) enext = excl_indices[ecur];
+  }
   float thr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
 
   // item tile staging: ST_TILE rows x (D/8) 16-byte chunks; chunk c of row i is stored at chunk position c ^ (i & SWZ)
   constexpr int CHUNKS = ST_TILE * (D / 8);
-  constexpr int PER_T = (CHUNKS + ST_THREADS - 1) / ST_THREADS;
+  constexpr int PER_T = (CHUNKS + THREADS - 1) / THREADS;
   uint4 stage[PER_T];
   auto g_load = [&](int j0) {
 #pragma unroll
     for (int p = 0; p < PER_T; ++p) {
-      const int ch = t + p * ST_THREADS;
+      const int ch = t + p * THREADS;
       const int i = ch / (D / 8), c = ch % (D / 8);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (ch < CHUNKS && j0 + i < I) v = *reinterpret_cast<const uint4*>(It + (long)(j0 + i) * D + c * 8);
@@ -159,7 +149,7 @@ __global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
   auto s_store = [&](unsigned char* tile) {
 #pragma unroll
     for (int p = 0; p < PER_T; ++p) {
-      const int ch = t + p * ST_THREADS;
+      const int ch = t + p * THREADS;
       if (ch < CHUNKS) {
         const int i = ch / (D / 8), c = ch % (D / 8);
         *reinterpret_cast<uint4*>(tile + i * ROWB + ((c ^ (i & SWZ)) << 4)) = stage[p];
@@ -188,8 +178,16 @@ __global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
         acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], b, acc[nj], 0, 0, 0);
       }
     }
-    // epilogue: threshold filter
+    // exclusion mask of this tile for row l31
     const int j0 = tl * ST_TILE;
+    const int gbase = item_offset + j0;
+    unsigned long long rmask = row_valid ? 0ull : ~0ull;
+    while (enext < gbase + ST_TILE) {
+      rmask |= 1ull << (enext - gbase);
+      ++ecur;
+      enext = ecur < eend ? excl_indices[ecur] : 0x7FFFFFFF;
+    }
+    // epilogue: threshold filter; survivors are appended to their row's buffer
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
       const int item = j0 + nj * 32 + l31;
@@ -197,10 +195,20 @@ __global__ __launch_bounds__(ST_THREADS) void score_topk_f16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[nj][r];
-        const bool cand = in_range && (v > thr[r]);
+        bool cand = in_range && (v > thr[r]);
         if (__ballot(cand)) {
-          const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          thr[r] = st_insert(st, v, cand, lrow, item_offset + item, thr[r], excl_indices, lane);
+          const int rw = (r & 3) + 8 * (r >> 2) + 4 * half;            // row within the wave's 32
+          const unsigned long long m = __shfl(rmask, rw, 64);
+          cand = cand && !((m >> (nj * 32 + l31)) & 1ull);
+          const int lrow = wave * 32 + rw;
+          const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) |
+                                         (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + item));
+          bool pending = cand;
+          if (pending) {
+            const int pos = atomicAdd(&st.cnt[lrow], 1);
+            if (pos < cap) { st.buf[lrow * cap + pos] = key; pending = false; }
+          }
+          if (__ballot(pending)) thr[r] = st_overflow(st, v, pending, lrow, key, thr[r], lane);
         }
       }
     }
@@ -233,17 +241,18 @@ static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64
 
 extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
 
-template <int KS>
+template <int KS, int WAVES>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, hipStream_t s) {
+  constexpr int ROWS = WAVES * 32;
   const int cap = st_cap(k);
-  const size_t lds = 2 * (size_t)ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_ROWS * (8 + 8 + 4);
+  const size_t lds = 2 * (size_t)ST_TILE * KS * 32 + (size_t)ROWS * cap * 8 + ROWS * 4;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  score_topk_f16_kernel<KS><<<sbr_cdiv(Bu, ST_ROWS), ST_THREADS, lds, s>>>(
+  score_topk_f16_kernel<KS, WAVES><<<sbr_cdiv(Bu, ROWS), WAVES * 64, lds, s>>>(
       (const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k, cap, out_val, out_idx);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
   return SBR_OK;
@@ -260,9 +269,9 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 64: return st_launch<4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
-    case 128: return st_launch<8>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
-    case 256: return st_launch<16>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 64: return st_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 128: return st_launch<8, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 256: return st_launch<16, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
       return SBR_ERR_ARG;

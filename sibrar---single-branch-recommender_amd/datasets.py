@@ -17,7 +17,8 @@ import scipy.sparse as sp
 import torch
 
 from .features import HostFeature
-from .sampling import PositiveIndex, loader_epoch_order, recbole_negative_collate, uniform_negative_collate
+from .sampling import (DevicePositiveIndex, PositiveIndex, loader_epoch_order, recbole_negative_collate,
+                       uniform_negative_collate)
 
 
 def synthetic_interactions(n_users: int, n_items: int, nnz: int, seed: int = 0) -> sp.csr_matrix:
@@ -99,7 +100,10 @@ class NegativeSamplingDataLoader:
     """Default training loader of the reference (data/dataloader.py:134-198 + shuffle) with the vectorised collate."""
 
     def __init__(self, dataset, batch_size: int = 256, shuffle: bool = True, strategy: Optional[str] = None,
-                 rank: int = 0, world: int = 1, max_batches: Optional[int] = None):
+                 rank: int = 0, world: int = 1, max_batches: Optional[int] = None, device=None, prefetch: int = 0):
+        """``device``: run the collision test of the collate on that GPU (DevicePositiveIndex) instead of numpy.
+        ``prefetch`` > 0: a producer thread prepares up to that many batches ahead (single producer, so the RNG streams are
+        consumed in the same order as without it)."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.strategy = strategy or dataset.negative_sampling_strategy
         if self.strategy not in ('uniform_recbole', 'uniform'):
@@ -107,14 +111,44 @@ class NegativeSamplingDataLoader:
         self.n_neg = dataset.n_negative_samples
         coo = dataset.interaction_matrix
         self.rows, self.cols = coo.row.astype(np.int64), coo.col.astype(np.int64)
-        self.positives = PositiveIndex(dataset.user_sampling_matrix)
+        self.positives = (DevicePositiveIndex(dataset.user_sampling_matrix, device) if device is not None
+                          else PositiveIndex(dataset.user_sampling_matrix))
         self.rank, self.world, self.max_batches = rank, world, max_batches
+        self.prefetch = prefetch
 
     def __len__(self):
         n = (len(self.rows) + self.batch_size - 1) // self.batch_size
         return n if self.max_batches is None else min(n, self.max_batches)
 
     def __iter__(self):
+        if self.prefetch <= 0:
+            return self._produce()
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        done = object()
+
+        def worker():
+            try:
+                for b in self._produce():
+                    q.put(b)
+                q.put(done)
+            except BaseException as e:      # surface producer errors in the consumer
+                q.put(e)
+
+        threading.Thread(target=worker, daemon=True).start()
+
+        def consume():
+            while True:
+                b = q.get()
+                if b is done:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                yield b
+        return consume()
+
+    def _produce(self):
         n = len(self.rows)
         order = loader_epoch_order(n) if self.shuffle else np.arange(n)
         for b in range(len(self)):

@@ -39,10 +39,38 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches on the stream they are launched on (torch's current stream is
+    the stream handed to the C ABI). bench.py enables it over the timed region to measure the dominant kernel live."""
+    enabled = False
+    records = {}          # key -> [(start_event, stop_event)]
+
+    @classmethod
+    def reset(cls, enabled: bool):
+        cls.enabled, cls.records = enabled, {}
+
+    @classmethod
+    def results(cls):
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in cls.records.items()}
+
+
+def _timed(key, fn):
+    if not KernelTimer.enabled:
+        return fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    KernelTimer.records.setdefault(key, []).append((a, b))
+    return out
+
+
 # ---- raw kernel helpers (no autograd) -------------------------------------------------------------------------------
 def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, act=0, atomic=0):
-    call('sbr_gemm_f32', mode, ptr(A), lda, ptr(a_idx), ptr(B), ldb, ptr(b_idx), ptr(bias), ptr(C), ldc, ptr(c_idx),
-         M, N, K, act, atomic, stream())
+    _timed(('gemm_f32', mode, M, N, K, a_idx is not None or b_idx is not None),
+           lambda: call('sbr_gemm_f32', mode, ptr(A), lda, ptr(a_idx), ptr(B), ldb, ptr(b_idx), ptr(bias), ptr(C), ldc,
+                        ptr(c_idx), M, N, K, act, atomic, stream()))
 
 
 def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None):
@@ -382,8 +410,9 @@ def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, exc
     I = i16.shape[0]
     val = torch.empty(Bu, k, device=u16.device, dtype=torch.float32)
     idx = torch.empty(Bu, k, device=u16.device, dtype=torch.int32)
-    call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), item_offset, k,
-         ptr(val), ptr(idx), None, 0, stream())
+    _timed(('score_topk_f16', Bu, I, D, k),
+           lambda: call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices),
+                        item_offset, k, ptr(val), ptr(idx), None, 0, stream()))
     return val, idx
 
 

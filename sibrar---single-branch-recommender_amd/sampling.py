@@ -84,6 +84,37 @@ class PositiveIndex:
         return (self.keys[pos] == q) if len(self.keys) else np.zeros(len(q), dtype=bool)
 
 
+class DevicePositiveIndex:
+    """The same membership test on the GPU: the split's interaction CSR is resident in HBM, each round uploads the
+    still-colliding (user, item) pairs, a kernel binary-searches the users' rows and the flags come back. It runs on a
+    private stream so that it never waits for queued training kernels. The random draws stay on the host (bit-exact
+    streams); only the `v in positives` test (data/dataloader.py:184-191) moves."""
+
+    def __init__(self, csr, device):
+        import torch
+        from . import ops  # noqa: F401  (fails loudly when the HIP library is missing)
+        csr = csr.tocsr()
+        csr.sort_indices()
+        self.device = torch.device(device)
+        self.indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(self.device)
+        self.indices = torch.from_numpy(csr.indices.astype(np.int32)).to(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
+        import torch
+        from ._lib import call, ptr
+        n = len(users)
+        if n == 0:
+            return np.zeros(0, dtype=bool)
+        with torch.cuda.stream(self.stream):
+            u = torch.from_numpy(np.ascontiguousarray(users, dtype=np.int64)).to(self.device, non_blocking=True)
+            i = torch.from_numpy(np.ascontiguousarray(items, dtype=np.int64)).to(self.device, non_blocking=True)
+            out = torch.empty(n, dtype=torch.uint8, device=self.device)
+            call('sbr_csr_contains', ptr(self.indptr), ptr(self.indices), ptr(u), ptr(i), n, ptr(out), self.stream.cuda_stream)
+            res = out.cpu()
+        return res.numpy().astype(bool)
+
+
 def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, items_in_split: np.ndarray,
                              positives: PositiveIndex):
     """data/dataloader.py:154-198 with the same global-RNG calls: draw all B*n_neg slots, redraw only the colliding ones
