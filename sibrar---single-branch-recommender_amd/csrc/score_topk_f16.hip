@@ -3,21 +3,29 @@
 //   out[b, excl(u_b)] = -inf (eval.py:219-220) applied to the few values that matter,
 //   running exact top-k per user kept on chip; output sorted by (score desc, item index asc).
 //
-// Geometry: one workgroup = 4 wavefronts = 128 users (two workgroups per CU); wave w owns users [32w, 32w+32) of the block
-// for the whole kernel and keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is
-// streamed once per workgroup through a double-buffered, XOR-swizzled LDS tile of 64 items; every wave multiplies its 32
-// users by the 64 items (2 x D/16 MFMAs per tile). Each accumulator value is compared with its row's current k-th best score
-// held in a register; only the rare survivors are tested against the tile's exclusion bit mask (each lane walks the sorted
-// exclusion row of one user in step with the tiles) and appended to the row's candidate buffer in LDS. A full buffer is
-// compacted by its owning wave (rank by counting), which raises the row's threshold. Rows are owned by exactly one wave, so
-// no cross-wave synchronisation is needed for the top-k state.
+// Geometry: one workgroup = 8 wavefronts = 256 users, one workgroup per CU. Wave w owns users [32w, 32w+32) of the block for
+// the whole kernel and keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is streamed
+// once per workgroup through a ring of XOR-swizzled 64-item LDS tiles filled by LDS-DMA (global_load_lds_dwordx4, swizzle on
+// the per-lane SOURCE address): up to NS-1 tiles are in flight behind a counted s_waitcnt vmcnt and one raw s_barrier per
+// tile, so the L2 -> LDS latency is hidden behind the MFMAs of the preceding tiles. Every wave multiplies its 32 users by the
+// 64 items of a tile (2 x D/16 MFMAs).
+//
+// Top-k: each accumulator value is compared with its row's current k-th best score held in a register (16 v_cmp per 32x32
+// tile, OR-reduced to one branch). Only the rare survivors are tested against the tile's exclusion bit mask (each lane walks
+// the sorted exclusion CSR row of one user in step with the tiles) and appended to the row's candidate buffer in LDS. A full
+// buffer is compacted by its owning wave (rank by counting), which raises the row's threshold. Rows are owned by exactly one
+// wave, so the top-k state needs no cross-wave synchronisation.
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ST_TILE 64        // items per LDS tile
+#define ST_WAVES 8
+#define ST_ROWS (ST_WAVES * 32)
+#define ST_THREADS (ST_WAVES * 64)
 
 __device__ __forceinline__ unsigned int st_f2key(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -76,31 +84,37 @@ __device__ __noinline__ float st_overflow(TopkState st, float v, bool pending, i
   return thr;
 }
 
-template <int KS, int WAVES>   // KS = D / 16; WAVES x 32 users per workgroup
-__global__ __launch_bounds__(WAVES * 64, (KS >= 16 ? 1 : 2)) void score_topk_f16_kernel(
+template <int N>
+__device__ __forceinline__ void st_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KS, int NS>   // KS = D / 16; NS = LDS ring slots (NS - 1 tiles in flight)
+__global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
-    float* __restrict__ out_val, int* __restrict__ out_idx) {
+    float* __restrict__ out_val, int* __restrict__ out_idx, int dbg) {
   constexpr int D = KS * 16;
-  constexpr int ROWS = WAVES * 32;
-  constexpr int THREADS = WAVES * 64;
-  constexpr int ROWB = D * 2;              // bytes per item row
-  constexpr int TILEB = ST_TILE * ROWB;    // bytes per LDS tile
-  constexpr int SWZ = (D / 8 >= 16) ? 15 : (D / 8 - 1);   // XOR swizzle mask over the 16-byte chunks of a row
+  constexpr int ROWB = D * 2;                              // bytes per item row
+  constexpr int TILEB = ST_TILE * ROWB;                    // bytes per LDS tile
+  constexpr int CPR = D / 8;                               // 16-byte chunks per item row
+  constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);        // XOR swizzle mask over the chunks of a row
+  constexpr int PER_W = (ST_TILE * CPR) / (ST_WAVES * 64); // 1-KiB LDS-DMA instructions per wave and tile
+  constexpr int PF = NS - 1;                               // tiles in flight
+  static_assert(PER_W >= 1 && (ST_TILE * CPR) % (ST_WAVES * 64) == 0, "tile must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tile0 = smem;
-  unsigned char* tile1 = smem + TILEB;
   TopkState st;
-  st.buf = reinterpret_cast<unsigned long long*>(smem + 2 * TILEB);
-  st.cnt = reinterpret_cast<int*>(smem + 2 * TILEB + (size_t)ROWS * cap * 8);
+  st.buf = reinterpret_cast<unsigned long long*>(smem + NS * TILEB);
+  st.cnt = reinterpret_cast<int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);
   st.cap = cap;
   st.k = k;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const long row0 = (long)blockIdx.x * ROWS;
+  const long row0 = (long)blockIdx.x * ST_ROWS;
 
-  if (t < ROWS) st.cnt[t] = 0;
+  if (lane < 32) st.cnt[wave * 32 + lane] = 0;          // each wave initialises the rows it owns
 
   // A fragments: user row (32*wave + l31), k = 16*s + 8*half + j
   f16x8 afrag[KS];
@@ -132,39 +146,37 @@ __global__ __launch_bounds__(WAVES * 64, (KS >= 16 ? 1 : 2)) void score_topk_f16
 #pragma unroll
   for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
 
-  // item tile staging: ST_TILE rows x (D/8) 16-byte chunks; chunk c of row i is stored at chunk position c ^ (i & SWZ)
-  constexpr int CHUNKS = ST_TILE * (D / 8);
-  constexpr int PER_T = (CHUNKS + THREADS - 1) / THREADS;
-  uint4 stage[PER_T];
-  auto g_load = [&](int j0) {
+  // LDS-DMA fill of one tile: wave w issues PER_W instructions, each writing 64 consecutive 16-byte chunk positions
+  // (1 KiB) of the slot; chunk position (row i, cp) receives source chunk cp ^ (i & SWZ) of item row j0 + i.
+  auto issue_tile = [&](int tile_idx) {
+    const int j0 = tile_idx * ST_TILE;
+    unsigned char* slot = smem + (tile_idx % NS) * TILEB;
 #pragma unroll
-    for (int p = 0; p < PER_T; ++p) {
-      const int ch = t + p * THREADS;
-      const int i = ch / (D / 8), c = ch % (D / 8);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ch < CHUNKS && j0 + i < I) v = *reinterpret_cast<const uint4*>(It + (long)(j0 + i) * D + c * 8);
-      stage[p] = v;
-    }
-  };
-  auto s_store = [&](unsigned char* tile) {
-#pragma unroll
-    for (int p = 0; p < PER_T; ++p) {
-      const int ch = t + p * THREADS;
-      if (ch < CHUNKS) {
-        const int i = ch / (D / 8), c = ch % (D / 8);
-        *reinterpret_cast<uint4*>(tile + i * ROWB + ((c ^ (i & SWZ)) << 4)) = stage[p];
-      }
+    for (int q = 0; q < PER_W; ++q) {
+      const int cb = wave * PER_W + q;                     // 1-KiB block of the tile (wave-uniform)
+      const int P = cb * 64 + lane;
+      const int i = P / CPR, cp = P % CPR;
+      int gi = j0 + i;
+      gi = gi < I ? gi : I - 1;                            // clamp: values of padded columns are never used
+      const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + cb * 1024), 16, 0, 0);
     }
   };
 
   const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
-  g_load(0);
-  s_store(tile0);
-  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < n_tiles) issue_tile(p);
+
   for (int tl = 0; tl < n_tiles; ++tl) {
-    unsigned char* cur = (tl & 1) ? tile1 : tile0;
-    unsigned char* nxt = (tl & 1) ? tile0 : tile1;
-    if (tl + 1 < n_tiles) g_load((tl + 1) * ST_TILE);
+    // tile tl has landed once at most (PF-1)*PER_W younger LDS-DMA instructions of this wave are outstanding
+    if (tl + PF - 1 < n_tiles) st_wait_vmcnt<(PF - 1) * PER_W>();
+    else st_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                          // every wave's part of tile tl is in LDS; tile tl-1 fully consumed
+    if (tl + PF < n_tiles) issue_tile(tl + PF);            // refill the slot that tile tl-1 occupied
+    const unsigned char* cur = smem + (tl % NS) * TILEB;
+
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -187,11 +199,17 @@ __global__ __launch_bounds__(WAVES * 64, (KS >= 16 ? 1 : 2)) void score_topk_f16
       ++ecur;
       enext = ecur < eend ? excl_indices[ecur] : 0x7FFFFFFF;
     }
+    if (dbg == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
     // epilogue: threshold filter; survivors are appended to their row's buffer
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
       const int item = j0 + nj * 32 + l31;
       const bool in_range = item < I;
+      unsigned long long any = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) any |= __ballot(acc[nj][r] > thr[r]);
+      if (dbg == 2) { if (any) asm volatile("s_nop 0"); continue; }
+      if (!any) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[nj][r];
@@ -212,8 +230,6 @@ __global__ __launch_bounds__(WAVES * 64, (KS >= 16 ? 1 : 2)) void score_topk_f16
         }
       }
     }
-    if (tl + 1 < n_tiles) s_store(nxt);
-    __syncthreads();
   }
 
   // final compaction + output: wave-owned rows
@@ -241,19 +257,19 @@ static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64
 
 extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
 
-template <int KS, int WAVES>
+template <int KS, int NS>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, hipStream_t s) {
-  constexpr int ROWS = WAVES * 32;
   const int cap = st_cap(k);
-  const size_t lds = 2 * (size_t)ST_TILE * KS * 32 + (size_t)ROWS * cap * 8 + ROWS * 4;
+  const size_t lds = (size_t)NS * ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_ROWS * 4;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  score_topk_f16_kernel<KS, WAVES><<<sbr_cdiv(Bu, ROWS), WAVES * 64, lds, s>>>(
-      (const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k, cap, out_val, out_idx);
+  score_topk_f16_kernel<KS, NS><<<sbr_cdiv(Bu, ST_ROWS), ST_THREADS, lds, s>>>(
+      (const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k, cap, out_val, out_idx,
+      getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
   return SBR_OK;
 }
@@ -271,7 +287,7 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   switch (D) {
     case 64: return st_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
     case 128: return st_launch<8, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
-    case 256: return st_launch<16, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 256: return st_launch<16, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
       return SBR_ERR_ARG;
