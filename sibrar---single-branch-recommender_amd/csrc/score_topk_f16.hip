@@ -37,50 +37,32 @@ __device__ __forceinline__ float st_key2f(unsigned int k) {
 
 struct TopkState {
   unsigned long long* buf;   // [rows][cap] composite keys (score key << 32 | ~item)
-  int* cnt;                  // [rows]
   int cap, k;
 };
 
-// all 64 lanes of the owning wave: keep the k best of row r's buffer, sorted; returns the new threshold
-__device__ __forceinline__ float st_compact(const TopkState& st, int r, int lane) {
+// Lanes of one wave exchange candidate entries through LDS without any hardware synchronisation (LDS operations of a wave
+// execute in order); the wavefront-scope fence only stops the compiler from caching / forwarding values across the exchange.
+__device__ __forceinline__ void st_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// all 64 lanes of the owning wave: keep the k best of the first n (wave-uniform) entries of row r's buffer, sorted;
+// returns the new threshold (-inf while fewer than k entries exist)
+__device__ __forceinline__ float st_compact(const TopkState& st, int r, int n, int lane) {
   unsigned long long* b = st.buf + r * st.cap;
-  int n = st.cnt[r];
-  n = n < st.cap ? n : st.cap;
+  st_wave_fence();
   const unsigned long long mine = lane < n ? b[lane] : 0ull;
+  // rank by counting, keys broadcast lane by lane with v_readlane (no LDS round trips inside the loop)
+  const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
   int rank = 0;
-  for (int j = 0; j < n; ++j) rank += (b[j] > mine);
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                  (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)lo, j);
+    rank += (kj > mine);
+  }
   if (lane < n && rank < st.k) b[rank] = mine;
-  const int kept = n < st.k ? n : st.k;
-  if (lane == 0) st.cnt[r] = kept;
+  st_wave_fence();
   const unsigned long long who = __ballot(lane < n && rank == st.k - 1);
   float thr = -INFINITY;
-  if (who) thr = st_key2f((unsigned int)(__shfl(mine, __ffsll((long long)who) - 1, 64) >> 32));
-  return thr;
-}
-
-// overflow path of one accumulator register step: some lanes could not append because their row's buffer is full.
-// Compacts those rows (raising their thresholds) and retries until every pending candidate is stored or beaten.
-// Returns the (possibly raised) threshold of this lane's row.
-__device__ __noinline__ float st_overflow(TopkState st, float v, bool pending, int row, unsigned long long key, float thr,
-                                          int lane) {
-  for (;;) {
-    unsigned long long ov = __ballot(pending);
-    if (!ov) break;
-    while (ov) {
-      const int src = __ffsll((long long)ov) - 1;
-      const int r = __shfl(row, src, 64);
-      const float nt = st_compact(st, r, lane);
-      if (row == r) {
-        thr = nt;
-        if (pending && !(v > thr)) pending = false;
-      }
-      ov &= ~__ballot(row == r);
-    }
-    if (pending) {
-      const int pos = atomicAdd(&st.cnt[row], 1);
-      if (pos < st.cap) { st.buf[row * st.cap + pos] = key; pending = false; }
-    }
-  }
+  if (who) thr = st_key2f((unsigned int)__builtin_amdgcn_readlane((int)hi, __ffsll((long long)who) - 1));
   return thr;
 }
 
@@ -89,11 +71,11 @@ __device__ __forceinline__ void st_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int NS>   // KS = D / 16; NS = LDS ring slots (NS - 1 tiles in flight)
+template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots (NS - 1 tiles in flight); DBG: timing ablations
 __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
-    float* __restrict__ out_val, int* __restrict__ out_idx, int dbg) {
+    float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
   constexpr int ROWB = D * 2;                              // bytes per item row
   constexpr int TILEB = ST_TILE * ROWB;                    // bytes per LDS tile
@@ -105,7 +87,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TopkState st;
   st.buf = reinterpret_cast<unsigned long long*>(smem + NS * TILEB);
-  st.cnt = reinterpret_cast<int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);
+  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);   // [ST_THREADS] per-lane exclusion bits of a tile
+  int* enx = reinterpret_cast<int*>(exw + ST_THREADS);    // [ST_THREADS] look-ahead exclusion entry of each lane's row (filled by LDS-DMA)
+  float* thr_lds = reinterpret_cast<float*>(enx + ST_THREADS);   // [ST_ROWS] thresholds handed from the compaction loop to the row's lanes
   st.cap = cap;
   st.k = k;
 
@@ -114,7 +98,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   const int l31 = lane & 31, half = lane >> 5;
   const long row0 = (long)blockIdx.x * ST_ROWS;
 
-  if (lane < 32) st.cnt[wave * 32 + lane] = 0;          // each wave initialises the rows it owns
+  exw[t] = 0u;
 
   // A fragments: user row (32*wave + l31), k = 16*s + 8*half + j
   f16x8 afrag[KS];
@@ -125,42 +109,61 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s) afrag[s] = src[2 * s + half];
   }
-  // exclusion cursor of row l31 of this wave (eval/eval.py:219-220): the user's sorted CSR row is consumed in step with the
-  // item tiles; per tile a 64-bit mask of the excluded columns is kept in a register (both lane halves hold a copy).
-  long ecur = 0, eend = 0;
-  int enext = 0x7FFFFFFF;
-  const bool row_valid = my_row < Bu;
-  if (row_valid && excl_indptr) {
-    const long u = u_idx ? u_idx[my_row] : my_row;
-    long lo = excl_indptr[u];
-    eend = excl_indptr[u + 1];
-    long hi = eend;
-    while (lo < hi) {                                      // first entry >= item_offset (item-sharded catalogues)
-      const long mid = (lo + hi) >> 1;
-      if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
+  // exclusion cursor of row l31 of this wave (eval/eval.py:219-220): lane l31 of the lower half walks user row l31's sorted
+  // CSR row in step with the item tiles. e0 = next excluded item (register), the one after it sits in LDS (enx[t]) where
+  // it is delivered by a 4-byte LDS-DMA: inside the main loop there is NO ordinary global load (hipcc would otherwise
+  // insert s_waitcnt vmcnt(0) and drain the tile pipeline every iteration).
+  long eidx = 0, eend = 0;              // CSR position of the entry held in enx[t]; end of the row
+  int e0 = 0x7FFFFFFF;
+  {
+    int e1 = 0x7FFFFFFF;
+    if (half == 0 && my_row < Bu && excl_indptr) {
+      const long u = u_idx ? u_idx[my_row] : my_row;
+      long lo = excl_indptr[u];
+      eend = excl_indptr[u + 1];
+      long hi = eend;
+      while (lo < hi) {                                    // first entry >= item_offset (item-sharded catalogues)
+        const long mid = (lo + hi) >> 1;
+        if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
+      }
+      if (lo < eend) e0 = excl_indices[lo];
+      if (lo + 1 < eend) e1 = excl_indices[lo + 1];
+      eidx = lo + 1;
     }
-    ecur = lo;
-    if (ecur < eend) enext = excl_indices[ecur];
+    enx[t] = e1;
   }
+  __attribute__((address_space(3))) int* enx_lds = (__attribute__((address_space(3))) int*)enx;
+  bool e_pending = false;               // wave-uniform: an exclusion look-ahead DMA of this wave may still be in flight
+  // per-row state replicated in the 32 lanes that see the row's accumulators: threshold and buffer fill count of the rows
+  // (r & 3) + 8 * (r >> 2) + 4 * half, r = 0..15
   float thr[16];
+  int fill[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+  for (int r = 0; r < 16; ++r) { thr[r] = -INFINITY; fill[r] = 0; }
 
   // LDS-DMA fill of one tile: wave w issues PER_W instructions, each writing 64 consecutive 16-byte chunk positions
   // (1 KiB) of the slot; chunk position (row i, cp) receives source chunk cp ^ (i & SWZ) of item row j0 + i.
+  // The per-lane part of the source address (row within the tile, swizzled chunk) is tile-invariant and precomputed.
+  int dma_row[PER_W], dma_off[PER_W];
+#pragma unroll
+  for (int q = 0; q < PER_W; ++q) {
+    const int P = (wave * PER_W + q) * 64 + lane;
+    const int i = P / CPR, cp = P % CPR;
+    dma_row[q] = i;
+    dma_off[q] = i * D + ((cp ^ (i & SWZ)) << 3);
+  }
   auto issue_tile = [&](int tile_idx) {
     const int j0 = tile_idx * ST_TILE;
     unsigned char* slot = smem + (tile_idx % NS) * TILEB;
+    const _Float16* base = It + (long)j0 * D;
+    const bool full = j0 + ST_TILE <= I;                   // wave-uniform
 #pragma unroll
     for (int q = 0; q < PER_W; ++q) {
-      const int cb = wave * PER_W + q;                     // 1-KiB block of the tile (wave-uniform)
-      const int P = cb * 64 + lane;
-      const int i = P / CPR, cp = P % CPR;
-      int gi = j0 + i;
-      gi = gi < I ? gi : I - 1;                            // clamp: values of padded columns are never used
-      const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
+      const _Float16* src = base + dma_off[q];
+      if (!full && j0 + dma_row[q] >= I)                   // last tile: clamp padded rows (their values are never used)
+        src = It + (long)(I - 1) * D + (dma_off[q] - dma_row[q] * D);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(slot + cb * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(slot + (wave * PER_W + q) * 1024), 16, 0, 0);
     }
   };
 
@@ -169,11 +172,15 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   for (int p = 0; p < PF; ++p)
     if (p < n_tiles) issue_tile(p);
 
+  unsigned long long t_wait = 0, t_evt = 0, t_ovf = 0, n_evt = 0, n_ovf = 0;
+  const unsigned long long t_begin = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int tl = 0; tl < n_tiles; ++tl) {
+    const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
     // tile tl has landed once at most (PF-1)*PER_W younger LDS-DMA instructions of this wave are outstanding
     if (tl + PF - 1 < n_tiles) st_wait_vmcnt<(PF - 1) * PER_W>();
     else st_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                          // every wave's part of tile tl is in LDS; tile tl-1 fully consumed
+    if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
     if (tl + PF < n_tiles) issue_tile(tl + PF);            // refill the slot that tile tl-1 occupied
     const unsigned char* cur = smem + (tl % NS) * TILEB;
 
@@ -190,65 +197,154 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
         acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], b, acc[nj], 0, 0, 0);
       }
     }
-    // exclusion mask of this tile for row l31
+    // exclusions of this tile (eval.py:219-220): an excluded (row, column) pair is delivered as ONE bit to the lane that
+    // holds that accumulator: lane (col & 31) + 32 * ((row >> 2) & 1), bit (col >> 5) * 16 + (row & 3) + 4 * (row >> 3).
     const int j0 = tl * ST_TILE;
     const int gbase = item_offset + j0;
-    unsigned long long rmask = row_valid ? 0ull : ~0ull;
-    while (enext < gbase + ST_TILE) {
-      rmask |= 1ull << (enext - gbase);
-      ++ecur;
-      enext = ecur < eend ? excl_indices[ecur] : 0x7FFFFFFF;
-    }
-    if (dbg == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
-    // epilogue: threshold filter; survivors are appended to their row's buffer
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      const int item = j0 + nj * 32 + l31;
-      const bool in_range = item < I;
-      unsigned long long any = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) any |= __ballot(acc[nj][r] > thr[r]);
-      if (dbg == 2) { if (any) asm volatile("s_nop 0"); continue; }
-      if (!any) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[nj][r];
-        bool cand = in_range && (v > thr[r]);
-        if (__ballot(cand)) {
-          const int rw = (r & 3) + 8 * (r >> 2) + 4 * half;            // row within the wave's 32
-          const unsigned long long m = __shfl(rmask, rw, 64);
-          cand = cand && !((m >> (nj * 32 + l31)) & 1ull);
-          const int lrow = wave * 32 + rw;
-          const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) |
-                                         (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + item));
-          bool pending = cand;
-          if (pending) {
-            const int pos = atomicAdd(&st.cnt[lrow], 1);
-            if (pos < cap) { st.buf[lrow * cap + pos] = key; pending = false; }
-          }
-          if (__ballot(pending)) thr[r] = st_overflow(st, v, pending, lrow, key, thr[r], lane);
+    bool wrote_ex = false;
+    for (int round = 0;; ++round) {
+      const bool take = e0 < gbase + ST_TILE;              // only lower-half lanes of valid rows ever hold a finite e0
+      if (!__ballot(take)) break;
+      // the look-ahead entries in LDS must have landed before they are shifted in: a counted wait covers the DMAs of
+      // earlier tiles; a second round inside one tile (two exclusions of one row within 64 items, rare) drains everything
+      if (round > 0) st_wait_vmcnt<0>();
+      else if (e_pending) st_wait_vmcnt<PER_W>();
+      e_pending = false;
+      wrote_ex = true;
+      if (take) {
+        const int col = e0 - gbase;
+        const int tgt = wave * 64 + (col & 31) + 32 * ((l31 >> 2) & 1);
+        atomicOr(&exw[tgt], 1u << ((col >> 5) * 16 + (l31 & 3) + 4 * (l31 >> 3)));
+        st_wave_fence();
+        e0 = enx_lds[t];                                  // ds_read_b32 (explicit LDS address space)
+        ++eidx;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // e0 is in its register before the slot is refilled
+        if (eidx < eend) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(excl_indices + eidx),
+                                           (__attribute__((address_space(3))) void*)(enx + wave * 64), 4, 0, 0);
+        } else {
+          enx_lds[t] = 0x7FFFFFFF;
+          st_wave_fence();
         }
       }
+      e_pending = true;
     }
+    if constexpr (DBG == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
+    // epilogue: threshold filter. Per 32x32 accumulator tile: 16 v_cmp whose ballots stay in SGPRs, OR-reduced to one branch.
+    // Survivors are appended to their row's buffer at positions derived from the ballot (v_mbcnt prefix count; no LDS
+    // atomics, no round trip: the append is a fire-and-forget ds_write). A candidate that finds its row's buffer full sets a
+    // retry bit; after the scan the full rows are compacted by ONE loop (no function call: a call would execute the ABI's
+    // s_waitcnt vmcnt(0) and drain the tile pipeline) and the scan is repeated for the retry bits only.
+    const bool have_ex = __ballot(wrote_ex) != 0ull;
+    unsigned int ex = 0u;
+    if (have_ex) { st_wave_fence(); ex = exw[t]; }
+    unsigned int retry = 0u;                               // bit nj*16 + r: my candidate of that step is not stored yet
+    for (int pass = 0; pass < 64; ++pass) {                // bounded; pass 0 = all steps, later passes = retry bits only
+      unsigned int retry_next = 0u;
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        unsigned long long br[16];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          br[r] = pass == 0 ? __ballot(acc[nj][r] > thr[r]) : __ballot((retry >> (nj * 16 + r)) & 1u);
+          any |= br[r];
+        }
+        if constexpr (DBG == 2) { if (any) asm volatile("s_nop 0"); continue; }
+        if (!any) continue;
+        const int item = j0 + nj * 32 + l31;
+        const bool in_range = item < I;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // the per-row registers are read into scalars, updated, and written back unconditionally: array elements are
+          // never assigned inside a branch (keeps thr[] / fill[] in fixed registers without whole-array copies)
+          int fill_r = fill[r];
+          if (br[r]) {                                                   // SGPR test: no VALU work on the common path
+            const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+            const float v = acc[nj][r];
+            const bool sel = pass == 0 ? (in_range && !((ex >> (nj * 16 + r)) & 1u)) : (((retry >> (nj * 16 + r)) & 1u) != 0u);
+            const bool cand = sel && (v > thr[r]);
+            const unsigned long long bal = __ballot(cand);
+            const unsigned int bal_lo = (unsigned int)bal, bal_hi = (unsigned int)(bal >> 32);
+            const int n_lo = __popc(bal_lo), n_hi = __popc(bal_hi);      // SALU
+            const int below = (int)__builtin_amdgcn_mbcnt_hi(bal_hi, __builtin_amdgcn_mbcnt_lo(bal_lo, 0u));
+            const int pos = fill_r + (half ? below - n_lo : below);     // rank among the candidates of MY row (my half)
+            const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (cand) {
+              if (pos < cap) {
+                st.buf[lrow * cap + pos] = ((unsigned long long)st_f2key(v) << 32) |
+                                           (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + item));
+              } else {
+                retry_next |= 1u << (nj * 16 + r);
+              }
+            }
+            fill_r += half ? n_hi : n_lo;                                // may exceed cap: marks the row as full
+            if constexpr (DBG == 4) { t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
+          }
+          fill[r] = fill_r;
+        }
+      }
+      retry = retry_next;
+      if (!__ballot(retry != 0u)) break;
+      // ---- compaction of the full rows (fill >= cap <=> exactly cap valid entries) -------------------------------------
+      const unsigned long long to0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+      unsigned int full_rows = 0u;                         // wave-uniform bit mask over the wave's 32 rows
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned long long fb = __ballot(fill[r] >= cap);
+        if (fb & 1ull) full_rows |= 1u << ((r & 3) + 8 * (r >> 2));
+        if (fb & (1ull << 32)) full_rows |= 1u << ((r & 3) + 8 * (r >> 2) + 4);
+      }
+      for (unsigned int m = full_rows; m; m &= m - 1u) {
+        const int q = __ffs((int)m) - 1;
+        const float nt = st_compact(st, wave * 32 + q, cap, lane);
+        if (lane == 0) thr_lds[wave * 32 + q] = nt;
+      }
+      st_wave_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool was_full = (full_rows >> rw) & 1u;
+        const float nt = thr_lds[wave * 32 + rw];
+        thr[r] = was_full ? nt : thr[r];
+        fill[r] = was_full ? k : fill[r];
+      }
+      if constexpr (DBG == 4) { t_ovf += __builtin_amdgcn_s_memtime() - to0; ++n_ovf; }
+    }
+    if (have_ex) exw[t] = 0u;
   }
 
-  // final compaction + output: wave-owned rows
-  for (int q = 0; q < 32; ++q) {
-    const int lrow = wave * 32 + q;
-    const long ur = row0 + lrow;
-    if (ur >= Bu) break;
-    st_compact(st, lrow, lane);
-    const int n = st.cnt[lrow];
-    if (lane < k) {
-      float val = -INFINITY;
-      int idx = -1;
-      if (lane < n) {
-        const unsigned long long c = st.buf[lrow * cap + lane];
-        val = st_key2f((unsigned int)(c >> 32));
-        idx = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
+  if constexpr (DBG == 4) {
+    if (lane == 0 && dbgbuf) {
+      unsigned long long* d = dbgbuf + ((long)blockIdx.x * ST_WAVES + wave) * 8;
+      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_evt; d[3] = t_ovf; d[4] = n_evt; d[5] = n_ovf;
+    }
+  }
+  // final compaction + output of the wave-owned rows: row (r & 3) + 8 * (r >> 2) + 4 * h has its fill count in register
+  // slot r of the lanes of half h
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const long ur = row0 + lrow;
+      if (ur >= Bu) continue;
+      int n = __shfl(fill[r], 32 * h, 64);
+      n = n < cap ? n : cap;
+      st_compact(st, lrow, n, lane);
+      st_wave_fence();
+      if (n > k) n = k;
+      if (lane < k) {
+        float val = -INFINITY;
+        int idx = -1;
+        if (lane < n) {
+          const unsigned long long c = st.buf[lrow * cap + lane];
+          val = st_key2f((unsigned int)(c >> 32));
+          idx = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
+        }
+        out_val[ur * k + lane] = val;
+        out_idx[ur * k + lane] = idx;
       }
-      out_val[ur * k + lane] = val;
-      out_idx[ur * k + lane] = idx;
     }
   }
 }
@@ -259,17 +355,21 @@ extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; 
 
 template <int KS, int NS>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
-                     int item_offset, int k, float* out_val, int* out_idx, hipStream_t s) {
+                     int item_offset, int k, float* out_val, int* out_idx, void* dbg_buf, hipStream_t s) {
   const int cap = st_cap(k);
-  const size_t lds = (size_t)NS * ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_ROWS * 4;
+  const size_t lds = (size_t)NS * ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_THREADS * 8 + ST_ROWS * 4;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  if (hipFuncSetAttribute((const void*)score_topk_f16_kernel<KS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // SBR_ST_DEBUG=1|2 selects timing-only ablation builds (1: MFMA main loop only, 2: + threshold compares); results are
+  // meaningless in those modes. Unset / 0 = the real kernel.
+  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;
+  auto kern = dbg == 1 ? score_topk_f16_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_kernel<KS, NS, 2> :
+              (dbg == 4 ? score_topk_f16_kernel<KS, NS, 4> : score_topk_f16_kernel<KS, NS, 0>));
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  score_topk_f16_kernel<KS, NS><<<sbr_cdiv(Bu, ST_ROWS), ST_THREADS, lds, s>>>(
-      (const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k, cap, out_val, out_idx,
-      getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0);
+  kern<<<sbr_cdiv(Bu, ST_ROWS), ST_THREADS, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx,
+                                                        item_offset, k, cap, out_val, out_idx, (unsigned long long*)dbg_buf);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
   return SBR_OK;
 }
@@ -277,7 +377,7 @@ static int st_launch(const void* U, const void* It, long Bu, int I, const long* 
 extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
                                   const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val,
                                   int* out_idx, void* workspace, long workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
+  (void)workspace_bytes;    // workspace: unused by the production kernel (SBR_ST_DEBUG=4 writes per-wave cycle stamps there)
   SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
   SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
   if (Bu == 0) return SBR_OK;
@@ -285,9 +385,9 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 64: return st_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
-    case 128: return st_launch<8, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
-    case 256: return st_launch<16, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, s);
+    case 64: return st_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 128: return st_launch<8, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 256: return st_launch<16, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
       return SBR_ERR_ARG;
