@@ -3,29 +3,32 @@
 //   out[b, excl(u_b)] = -inf (eval.py:219-220) applied to the few values that matter,
 //   running exact top-k per user kept on chip; output sorted by (score desc, item index asc).
 //
-// Geometry: one workgroup = 8 wavefronts = 256 users, one workgroup per CU. Wave w owns users [32w, 32w+32) of the block for
-// the whole kernel and keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs). The item matrix is streamed
-// once per workgroup through a ring of XOR-swizzled 64-item LDS tiles filled by LDS-DMA (global_load_lds_dwordx4, swizzle on
-// the per-lane SOURCE address): up to NS-1 tiles are in flight behind a counted s_waitcnt vmcnt and one raw s_barrier per
-// tile, so the L2 -> LDS latency is hidden behind the MFMAs of the preceding tiles. Every wave multiplies its 32 users by the
-// 64 items of a tile (2 x D/16 MFMAs).
+// Geometry: one workgroup per CU = 7 consumer wavefronts + 1 loader wavefront. Consumer wave w owns users [32w, 32w+32) of the
+// workgroup's 224-user block for the whole kernel and keeps their fp16 rows as MFMA A-fragments in registers (D/16 x 4 VGPRs).
+// The loader wave streams the item matrix once per workgroup through a ring of XOR-swizzled 64-item LDS tiles with LDS-DMA
+// (global_load_lds_dwordx4, swizzle on the per-lane SOURCE address) and hands tiles over through two LDS counters per slot
+// (FULL: published tile number, FREE: consumers done). There is NO workgroup barrier in the main loop: a consumer that is
+// busy with top-k bookkeeping only delays the others once the whole ring is used up.
 //
 // Top-k: each accumulator value is compared with its row's current k-th best score held in a register (16 v_cmp per 32x32
-// tile, OR-reduced to one branch). Only the rare survivors are tested against the tile's exclusion bit mask (each lane walks
-// the sorted exclusion CSR row of one user in step with the tiles) and appended to the row's candidate buffer in LDS. A full
-// buffer is compacted by its owning wave (rank by counting), which raises the row's threshold. Rows are owned by exactly one
-// wave, so the top-k state needs no cross-wave synchronisation.
+// tile whose ballots stay in SGPRs, OR-reduced to one branch). The rare survivors are tested against the tile's exclusion
+// bits (each lower-half lane walks the sorted exclusion CSR row of one user in step with the tiles; look-ahead entries arrive
+// by 4-byte LDS-DMA so that the loop contains no ordinary global load) and appended to the row's candidate buffer in LDS at
+// positions derived from the wave ballot (no atomics). A full buffer is compacted by its owning wave (rank by counting over
+// v_readlane broadcasts), which raises the row's threshold. Rows are owned by exactly one wave: the top-k state needs no
+// cross-wave synchronisation.
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) int lds_int;
 
-#define ST_TILE 64        // items per LDS tile
-#define ST_WAVES 8
-#define ST_ROWS (ST_WAVES * 32)
-#define ST_THREADS (ST_WAVES * 64)
+#define ST_TILE 64                       // items per LDS tile
+#define ST_WAVES 7                       // consumer waves
+#define ST_ROWS (ST_WAVES * 32)          // users per workgroup
+#define ST_THREADS ((ST_WAVES + 1) * 64) // + loader wave
 
 __device__ __forceinline__ unsigned int st_f2key(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -66,12 +69,59 @@ __device__ __forceinline__ float st_compact(const TopkState& st, int r, int n, i
   return thr;
 }
 
+// overflow path of one accumulator register step: some lanes could not append because their row's buffer is full.
+// Compacts those rows (raising their thresholds) and retries until every pending candidate is stored or beaten.
+// thr / cnt are the lane's register copies of its row's threshold and fill count (identical in the 32 lanes that share the
+// row); the updated pair is returned. (The ABI makes a called function wait for vmcnt(0): harmless here because the
+// consumer waves have no tile DMA of their own in flight — only the rare exclusion look-ahead.)
+struct RowState { float thr; int cnt; };
+
+__device__ __noinline__ RowState st_overflow(TopkState st, float v, bool pending, int row, unsigned long long key, float thr,
+                                             int cnt, int lane) {
+  for (int guard = 0; guard < 4096; ++guard) {             // bounded: every round stores or drops >= 1 candidate
+    const unsigned long long ov = __ballot(pending);
+    if (!ov) break;
+    const int src = __ffsll((long long)ov) - 1;
+    const int r = __shfl(row, src, 64);
+    int n = __shfl(cnt, src, 64);                          // fill count of row r (register copy of the source lane)
+    n = n < st.cap ? n : st.cap;
+    const float nt = st_compact(st, r, n, lane);
+    const int kept = n < st.k ? n : st.k;
+    const bool mine = row == r;
+    if (mine) {
+      thr = nt;
+      cnt = kept;
+      if (pending && !(v > thr)) pending = false;
+    }
+    // retry the still-pending candidates of row r: positions by ballot order
+    const unsigned long long pb = __ballot(mine && pending);
+    if (mine) {
+      if (pending) {
+        const int pos = cnt + __popcll(pb & ((1ull << lane) - 1ull));
+        if (pos < st.cap) { st.buf[r * st.cap + pos] = key; pending = false; }
+      }
+      cnt += __popcll(pb);
+    }
+  }
+  RowState out;
+  out.thr = thr;
+  out.cnt = cnt;
+  return out;
+}
+
 template <int N>
 __device__ __forceinline__ void st_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots (NS - 1 tiles in flight); DBG: timing ablations
+// wave-uniform read of an LDS word that another wave of the workgroup writes
+__device__ __forceinline__ int st_peek(lds_int* p) {
+  st_wave_fence();
+  const int v = *(volatile lds_int*)p;
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots; DBG: timing-only ablation builds
 __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
@@ -81,25 +131,64 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   constexpr int TILEB = ST_TILE * ROWB;                    // bytes per LDS tile
   constexpr int CPR = D / 8;                               // 16-byte chunks per item row
   constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);        // XOR swizzle mask over the chunks of a row
-  constexpr int PER_W = (ST_TILE * CPR) / (ST_WAVES * 64); // 1-KiB LDS-DMA instructions per wave and tile
-  constexpr int PF = NS - 1;                               // tiles in flight
-  static_assert(PER_W >= 1 && (ST_TILE * CPR) % (ST_WAVES * 64) == 0, "tile must split evenly over the waves");
+  constexpr int PER_T = (ST_TILE * CPR) / 64;              // 1-KiB LDS-DMA instructions per tile (all issued by the loader)
+  constexpr int LFL = NS > 2 ? NS - 2 : 1;                 // tiles the loader keeps in flight behind the one it waits for
+  static_assert(LFL * PER_T <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TopkState st;
   st.buf = reinterpret_cast<unsigned long long*>(smem + NS * TILEB);
-  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);   // [ST_THREADS] per-lane exclusion bits of a tile
-  int* enx = reinterpret_cast<int*>(exw + ST_THREADS);    // [ST_THREADS] look-ahead exclusion entry of each lane's row (filled by LDS-DMA)
-  float* thr_lds = reinterpret_cast<float*>(enx + ST_THREADS);   // [ST_ROWS] thresholds handed from the compaction loop to the row's lanes
   st.cap = cap;
   st.k = k;
+  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);  // [ST_WAVES*64] exclusion bits
+  int* enx = reinterpret_cast<int*>(exw + ST_WAVES * 64);                                               // [ST_WAVES*64] look-ahead entries
+  lds_int* full_lds = (lds_int*)(enx + ST_WAVES * 64);     // [NS] published tile number + 1 of each slot
+  lds_int* free_lds = full_lds + NS;                       // [NS] number of consumer waves done with the slot (monotonic)
+  lds_int* enx_lds = (lds_int*)enx;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const long row0 = (long)blockIdx.x * ST_ROWS;
+  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
 
-  exw[t] = 0u;
+  if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
+  __syncthreads();                                         // the only workgroup barrier of the kernel
 
+  if (wave == ST_WAVES) {
+    // ---------------------------------------------- loader wave ------------------------------------------------------
+    // chunk position (row i, cp) of a tile receives source chunk cp ^ (i & SWZ) of item row j0 + i
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int slot = tile % NS;
+      if (tile >= NS) {
+        const int need = ST_WAVES * (tile / NS);
+        while (st_peek(free_lds + slot) < need) __builtin_amdgcn_s_sleep(1);
+      }
+      const int j0 = tile * ST_TILE;
+      unsigned char* dst = smem + slot * TILEB;
+#pragma unroll
+      for (int q = 0; q < PER_T; ++q) {
+        const int P = q * 64 + lane;
+        const int i = P / CPR, cp = P % CPR;
+        int gi = j0 + i;
+        gi = gi < I ? gi : I - 1;                          // clamp: values of padded columns are never used
+        const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+      }
+      if (tile >= LFL) {                                   // tile - LFL has landed once only LFL tiles remain outstanding
+        st_wait_vmcnt<LFL * PER_T>();
+        st_wave_fence();
+        *(volatile lds_int*)(full_lds + (tile - LFL) % NS) = tile - LFL + 1;
+      }
+    }
+    st_wait_vmcnt<0>();
+    st_wave_fence();
+    for (int tile = (n_tiles > LFL ? n_tiles - LFL : 0); tile < n_tiles; ++tile)
+      *(volatile lds_int*)(full_lds + tile % NS) = tile + 1;
+    return;
+  }
+
+  // ------------------------------------------------ consumer waves ------------------------------------------------------
   // A fragments: user row (32*wave + l31), k = 16*s + 8*half + j
   f16x8 afrag[KS];
   const long my_row = row0 + wave * 32 + l31;            // the user row this lane loads and whose exclusion list it walks
@@ -109,10 +198,11 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s) afrag[s] = src[2 * s + half];
   }
+  exw[t] = 0u;
   // exclusion cursor of row l31 of this wave (eval/eval.py:219-220): lane l31 of the lower half walks user row l31's sorted
   // CSR row in step with the item tiles. e0 = next excluded item (register), the one after it sits in LDS (enx[t]) where
   // it is delivered by a 4-byte LDS-DMA: inside the main loop there is NO ordinary global load (hipcc would otherwise
-  // insert s_waitcnt vmcnt(0) and drain the tile pipeline every iteration).
+  // insert s_waitcnt vmcnt(0) at every iteration).
   long eidx = 0, eend = 0;              // CSR position of the entry held in enx[t]; end of the row
   int e0 = 0x7FFFFFFF;
   {
@@ -132,7 +222,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     }
     enx[t] = e1;
   }
-  __attribute__((address_space(3))) int* enx_lds = (__attribute__((address_space(3))) int*)enx;
   bool e_pending = false;               // wave-uniform: an exclusion look-ahead DMA of this wave may still be in flight
   // per-row state replicated in the 32 lanes that see the row's accumulators: threshold and buffer fill count of the rows
   // (r & 3) + 8 * (r >> 2) + 4 * half, r = 0..15
@@ -141,48 +230,15 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) { thr[r] = -INFINITY; fill[r] = 0; }
 
-  // LDS-DMA fill of one tile: wave w issues PER_W instructions, each writing 64 consecutive 16-byte chunk positions
-  // (1 KiB) of the slot; chunk position (row i, cp) receives source chunk cp ^ (i & SWZ) of item row j0 + i.
-  // The per-lane part of the source address (row within the tile, swizzled chunk) is tile-invariant and precomputed.
-  int dma_row[PER_W], dma_off[PER_W];
-#pragma unroll
-  for (int q = 0; q < PER_W; ++q) {
-    const int P = (wave * PER_W + q) * 64 + lane;
-    const int i = P / CPR, cp = P % CPR;
-    dma_row[q] = i;
-    dma_off[q] = i * D + ((cp ^ (i & SWZ)) << 3);
-  }
-  auto issue_tile = [&](int tile_idx) {
-    const int j0 = tile_idx * ST_TILE;
-    unsigned char* slot = smem + (tile_idx % NS) * TILEB;
-    const _Float16* base = It + (long)j0 * D;
-    const bool full = j0 + ST_TILE <= I;                   // wave-uniform
-#pragma unroll
-    for (int q = 0; q < PER_W; ++q) {
-      const _Float16* src = base + dma_off[q];
-      if (!full && j0 + dma_row[q] >= I)                   // last tile: clamp padded rows (their values are never used)
-        src = It + (long)(I - 1) * D + (dma_off[q] - dma_row[q] * D);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(slot + (wave * PER_W + q) * 1024), 16, 0, 0);
-    }
-  };
-
-  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p < n_tiles) issue_tile(p);
-
   unsigned long long t_wait = 0, t_evt = 0, t_ovf = 0, n_evt = 0, n_ovf = 0;
   const unsigned long long t_begin = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int tl = 0; tl < n_tiles; ++tl) {
+    const int slot = tl % NS;
     const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-    // tile tl has landed once at most (PF-1)*PER_W younger LDS-DMA instructions of this wave are outstanding
-    if (tl + PF - 1 < n_tiles) st_wait_vmcnt<(PF - 1) * PER_W>();
-    else st_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                          // every wave's part of tile tl is in LDS; tile tl-1 fully consumed
+    while (st_peek(full_lds + slot) != tl + 1) __builtin_amdgcn_s_sleep(1);
+    st_wave_fence();
     if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
-    if (tl + PF < n_tiles) issue_tile(tl + PF);            // refill the slot that tile tl-1 occupied
-    const unsigned char* cur = smem + (tl % NS) * TILEB;
+    const unsigned char* cur = smem + slot * TILEB;
 
     f32x16 acc[2];
 #pragma unroll
@@ -197,6 +253,10 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
         acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], b, acc[nj], 0, 0, 0);
       }
     }
+    // the tile's LDS reads have been consumed by the MFMAs above: hand the slot back to the loader
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0]), "v"(acc[1]) : "memory");
+    if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);
+
     // exclusions of this tile (eval.py:219-220): an excluded (row, column) pair is delivered as ONE bit to the lane that
     // holds that accumulator: lane (col & 31) + 32 * ((row >> 2) & 1), bit (col >> 5) * 16 + (row & 3) + 4 * (row >> 3).
     const int j0 = tl * ST_TILE;
@@ -205,10 +265,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     for (int round = 0;; ++round) {
       const bool take = e0 < gbase + ST_TILE;              // only lower-half lanes of valid rows ever hold a finite e0
       if (!__ballot(take)) break;
-      // the look-ahead entries in LDS must have landed before they are shifted in: a counted wait covers the DMAs of
-      // earlier tiles; a second round inside one tile (two exclusions of one row within 64 items, rare) drains everything
-      if (round > 0) st_wait_vmcnt<0>();
-      else if (e_pending) st_wait_vmcnt<PER_W>();
+      // the look-ahead entry in LDS must have landed before it is shifted in
+      if (e_pending) st_wait_vmcnt<0>();
       e_pending = false;
       wrote_ex = true;
       if (take) {
@@ -216,7 +274,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
         const int tgt = wave * 64 + (col & 31) + 32 * ((l31 >> 2) & 1);
         atomicOr(&exw[tgt], 1u << ((col >> 5) * 16 + (l31 & 3) + 4 * (l31 >> 3)));
         st_wave_fence();
-        e0 = enx_lds[t];                                  // ds_read_b32 (explicit LDS address space)
+        e0 = enx_lds[t];                                   // ds_read_b32 (explicit LDS address space)
         ++eidx;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // e0 is in its register before the slot is refilled
         if (eidx < eend) {
@@ -232,86 +290,57 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     if constexpr (DBG == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
     // epilogue: threshold filter. Per 32x32 accumulator tile: 16 v_cmp whose ballots stay in SGPRs, OR-reduced to one branch.
     // Survivors are appended to their row's buffer at positions derived from the ballot (v_mbcnt prefix count; no LDS
-    // atomics, no round trip: the append is a fire-and-forget ds_write). A candidate that finds its row's buffer full sets a
-    // retry bit; after the scan the full rows are compacted by ONE loop (no function call: a call would execute the ABI's
-    // s_waitcnt vmcnt(0) and drain the tile pipeline) and the scan is repeated for the retry bits only.
+    // atomics, no round trip: the append is a fire-and-forget ds_write).
     const bool have_ex = __ballot(wrote_ex) != 0ull;
     unsigned int ex = 0u;
-    if (have_ex) { st_wave_fence(); ex = exw[t]; }
-    unsigned int retry = 0u;                               // bit nj*16 + r: my candidate of that step is not stored yet
-    for (int pass = 0; pass < 64; ++pass) {                // bounded; pass 0 = all steps, later passes = retry bits only
-      unsigned int retry_next = 0u;
+    bool ex_loaded = false;
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        unsigned long long br[16];
-        unsigned long long any = 0;
+    for (int nj = 0; nj < 2; ++nj) {
+      unsigned long long br[16];
+      unsigned long long any = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          br[r] = pass == 0 ? __ballot(acc[nj][r] > thr[r]) : __ballot((retry >> (nj * 16 + r)) & 1u);
-          any |= br[r];
-        }
-        if constexpr (DBG == 2) { if (any) asm volatile("s_nop 0"); continue; }
-        if (!any) continue;
-        const int item = j0 + nj * 32 + l31;
-        const bool in_range = item < I;
+      for (int r = 0; r < 16; ++r) { br[r] = __ballot(acc[nj][r] > thr[r]); any |= br[r]; }
+      if constexpr (DBG == 2) { if (any) asm volatile("s_nop 0"); continue; }
+      if (!any) continue;
+      if (have_ex && !ex_loaded) { st_wave_fence(); ex = exw[t]; ex_loaded = true; }
+      const int item = j0 + nj * 32 + l31;
+      const bool in_range = item < I;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // the per-row registers are read into scalars, updated, and written back unconditionally: array elements are
-          // never assigned inside a branch (keeps thr[] / fill[] in fixed registers without whole-array copies)
-          int fill_r = fill[r];
-          if (br[r]) {                                                   // SGPR test: no VALU work on the common path
-            const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-            const float v = acc[nj][r];
-            const bool sel = pass == 0 ? (in_range && !((ex >> (nj * 16 + r)) & 1u)) : (((retry >> (nj * 16 + r)) & 1u) != 0u);
-            const bool cand = sel && (v > thr[r]);
-            const unsigned long long bal = __ballot(cand);
-            const unsigned int bal_lo = (unsigned int)bal, bal_hi = (unsigned int)(bal >> 32);
-            const int n_lo = __popc(bal_lo), n_hi = __popc(bal_hi);      // SALU
-            const int below = (int)__builtin_amdgcn_mbcnt_hi(bal_hi, __builtin_amdgcn_mbcnt_lo(bal_lo, 0u));
-            const int pos = fill_r + (half ? below - n_lo : below);     // rank among the candidates of MY row (my half)
-            const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (cand) {
-              if (pos < cap) {
-                st.buf[lrow * cap + pos] = ((unsigned long long)st_f2key(v) << 32) |
-                                           (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + item));
-              } else {
-                retry_next |= 1u << (nj * 16 + r);
-              }
-            }
-            fill_r += half ? n_hi : n_lo;                                // may exceed cap: marks the row as full
-            if constexpr (DBG == 4) { t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
+      for (int r = 0; r < 16; ++r) {
+        // the per-row registers are read into scalars, updated, and written back unconditionally: array elements are
+        // never assigned inside a branch (keeps thr[] / fill[] in fixed registers without whole-array copies)
+        float thr_r = thr[r];
+        int fill_r = fill[r];
+        if (br[r]) {                                                     // SGPR test: no VALU work on the common path
+          const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+          const float v = acc[nj][r];
+          // re-check against the current threshold (an earlier step of this tile may have raised it) and the exclusions
+          const bool cand = in_range && (v > thr_r) && !((ex >> (nj * 16 + r)) & 1u);
+          const unsigned long long bal = __ballot(cand);
+          const unsigned int bal_lo = (unsigned int)bal, bal_hi = (unsigned int)(bal >> 32);
+          const int n_lo = __popc(bal_lo), n_hi = __popc(bal_hi);        // SALU
+          const int below = (int)__builtin_amdgcn_mbcnt_hi(bal_hi, __builtin_amdgcn_mbcnt_lo(bal_lo, 0u));
+          const int pos = fill_r + (half ? below - n_lo : below);       // rank among the candidates of MY row (my half)
+          const int lrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) |
+                                         (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + item));
+          bool pending = cand;
+          if (cand && pos < cap) { st.buf[lrow * cap + pos] = key; pending = false; }
+          fill_r += half ? n_hi : n_lo;
+          if (__ballot(pending)) {
+            const unsigned long long to0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+            const RowState rs = st_overflow(st, v, pending, lrow, key, thr_r, fill_r, lane);
+            thr_r = rs.thr;
+            fill_r = rs.cnt;
+            if constexpr (DBG == 4) { t_ovf += __builtin_amdgcn_s_memtime() - to0; ++n_ovf; }
           }
-          fill[r] = fill_r;
+          if constexpr (DBG == 4) { t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
         }
+        thr[r] = thr_r;
+        fill[r] = fill_r;
       }
-      retry = retry_next;
-      if (!__ballot(retry != 0u)) break;
-      // ---- compaction of the full rows (fill >= cap <=> exactly cap valid entries) -------------------------------------
-      const unsigned long long to0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-      unsigned int full_rows = 0u;                         // wave-uniform bit mask over the wave's 32 rows
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned long long fb = __ballot(fill[r] >= cap);
-        if (fb & 1ull) full_rows |= 1u << ((r & 3) + 8 * (r >> 2));
-        if (fb & (1ull << 32)) full_rows |= 1u << ((r & 3) + 8 * (r >> 2) + 4);
-      }
-      for (unsigned int m = full_rows; m; m &= m - 1u) {
-        const int q = __ffs((int)m) - 1;
-        const float nt = st_compact(st, wave * 32 + q, cap, lane);
-        if (lane == 0) thr_lds[wave * 32 + q] = nt;
-      }
-      st_wave_fence();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rw = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool was_full = (full_rows >> rw) & 1u;
-        const float nt = thr_lds[wave * 32 + rw];
-        thr[r] = was_full ? nt : thr[r];
-        fill[r] = was_full ? k : fill[r];
-      }
-      if constexpr (DBG == 4) { t_ovf += __builtin_amdgcn_s_memtime() - to0; ++n_ovf; }
     }
-    if (have_ex) exw[t] = 0u;
+    if (have_ex) { exw[t] = 0u; st_wave_fence(); }
   }
 
   if constexpr (DBG == 4) {
@@ -357,10 +386,10 @@ template <int KS, int NS>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, void* dbg_buf, hipStream_t s) {
   const int cap = st_cap(k);
-  const size_t lds = (size_t)NS * ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_THREADS * 8 + ST_ROWS * 4;
+  const size_t lds = (size_t)NS * ST_TILE * KS * 32 + (size_t)ST_ROWS * cap * 8 + ST_WAVES * 64 * 8 + 2 * NS * 4 + 16;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  // SBR_ST_DEBUG=1|2 selects timing-only ablation builds (1: MFMA main loop only, 2: + threshold compares); results are
-  // meaningless in those modes. Unset / 0 = the real kernel.
+  // SBR_ST_DEBUG=1|2 selects timing-only ablation builds (1: MFMA main loop only, 2: + threshold compares; results are
+  // meaningless), 4 adds per-wave cycle stamps written to `workspace`. Unset / 0 = the real kernel.
   const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;
   auto kern = dbg == 1 ? score_topk_f16_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_kernel<KS, NS, 2> :
               (dbg == 4 ? score_topk_f16_kernel<KS, NS, 4> : score_topk_f16_kernel<KS, NS, 0>));
@@ -385,8 +414,8 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 64: return st_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    case 128: return st_launch<8, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 64: return st_launch<4, 6>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 128: return st_launch<8, 5>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     case 256: return st_launch<16, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
