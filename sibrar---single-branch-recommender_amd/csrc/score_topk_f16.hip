@@ -24,6 +24,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
 #define ST_TILE 64                       // items per LDS tile
 #define ST_WAVES 7                       // consumer waves
@@ -39,7 +40,8 @@ __device__ __forceinline__ float st_key2f(unsigned int k) {
 }
 
 struct TopkState {
-  unsigned long long* buf;   // [rows][cap] composite keys (score key << 32 | ~item)
+  lds_u64* buf;              // [rows][cap] composite keys (score key << 32 | ~item); explicit LDS address space: 32-bit
+                             // addresses and plain ds_read/ds_write also inside the non-inlined overflow path
   int cap, k;
 };
 
@@ -49,23 +51,26 @@ __device__ __forceinline__ void st_wave_fence() { __builtin_amdgcn_fence(__ATOMI
 
 // all 64 lanes of the owning wave: keep the k best of the first n (wave-uniform) entries of row r's buffer, sorted;
 // returns the new threshold (-inf while fewer than k entries exist)
-__device__ __forceinline__ float st_compact(const TopkState& st, int r, int n, int lane) {
-  unsigned long long* b = st.buf + r * st.cap;
+__device__ __forceinline__ float st_compact(const TopkState& st, int r, int n_any, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_any);     // wave-uniform: scalar loop control below
+  lds_u64* b = st.buf + r * st.cap;
   st_wave_fence();
   const unsigned long long mine = lane < n ? b[lane] : 0ull;
-  // rank by counting, keys broadcast lane by lane with v_readlane (no LDS round trips inside the loop)
-  const unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
+  // rank by counting: the n keys are read back as LDS broadcasts (uniform address), eight reads in flight per step
   int rank = 0;
-  for (int j = 0; j < n; ++j) {
-    const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, j) << 32) |
-                                  (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)lo, j);
-    rank += (kj > mine);
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    unsigned long long kj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kj[q] = b[j0 + q < n ? j0 + q : n - 1];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rank += (j0 + q < n) && (kj[q] > mine);
   }
+  st_wave_fence();
   if (lane < n && rank < st.k) b[rank] = mine;
   st_wave_fence();
   const unsigned long long who = __ballot(lane < n && rank == st.k - 1);
   float thr = -INFINITY;
-  if (who) thr = st_key2f((unsigned int)__builtin_amdgcn_readlane((int)hi, __ffsll((long long)who) - 1));
+  if (who) thr = st_key2f((unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), __ffsll((long long)who) - 1));
   return thr;
 }
 
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   static_assert(LFL * PER_T <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TopkState st;
-  st.buf = reinterpret_cast<unsigned long long*>(smem + NS * TILEB);
+  st.buf = (lds_u64*)(smem + NS * TILEB);
   st.cap = cap;
   st.k = k;
   unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB + (size_t)ST_ROWS * cap * 8);  // [ST_WAVES*64] exclusion bits

@@ -9,13 +9,13 @@ g = torch.Generator(device='cuda').manual_seed(1)
 Bu, I, D = 100000, 50000, int(sys.argv[1]) if len(sys.argv) > 1 else 128
 u = (torch.randn(Bu, D, device='cuda', generator=g) / 8).half()
 it = (torch.randn(I, D, device='cuda', generator=g) / 8).half()
-nwg = (Bu + 255) // 256
-dbg = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device='cuda')
+nwg = (Bu + 223) // 224
+dbg = torch.zeros(nwg * 7 * 8, dtype=torch.int64, device='cuda')
 val = torch.empty(Bu, 20, device='cuda'); idx = torch.empty(Bu, 20, dtype=torch.int32, device='cuda')
 for _ in range(2):
     L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 20, val.data_ptr(), idx.data_ptr(), dbg.data_ptr(), dbg.numel() * 8, L.stream())
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nwg * 8, 8).astype(np.float64)
+d = dbg.cpu().numpy().reshape(nwg * 7, 8).astype(np.float64)
 tot, wait, evt, ovf, nevt, novf = [d[:, i] for i in range(6)]
 print(f'per wave (mean over {len(d)} waves): total {tot.mean():.3g} cyc | barrier+dma wait {wait.mean():.3g} ({100*wait.mean()/tot.mean():.1f}%) | '
       f'event blocks {evt.mean():.3g} ({100*evt.mean()/tot.mean():.1f}%), n={nevt.mean():.0f}, {evt.mean()/max(nevt.mean(),1):.0f} cyc/event | '
