@@ -48,6 +48,12 @@ int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const flo
                  const float* bias, float* C, long ldc, const int* c_idx, int M, int N, int K, int act,
                  int accumulate_atomic, void* stream);
 
+/* TN with a deterministic split-K slab reducer (no atomics): C[m, n] = sum_k A[ak(k), m] * B[bk(k), n], C overwritten.
+ * autograd of nn.Linear w.r.t. its weight (dW = dZ^T X[rows]). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes. */
+long sbr_gemm_tn_f32_workspace(int M, int N, int K);
+int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C, long ldc,
+                    int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
+
 /* ---- index plumbing ----------------------------------------------------------------------------------------------------
  * rows_out[j] = rowmap_seg(j)[ idx[slots[j] / k] ] for the concatenated per-modality slot lists (segment s covers
  * [seg_offsets[s], seg_offsets[s+1])): the id -> row lookup of Feature.__getitem__ (data/Feature.py:146) on the

@@ -15,6 +15,7 @@
 // MFMAs of slab t). Within each 8-wide k group lane-half h supplies k = 4h + s to MFMA step s, so one 16-byte LDS
 // read feeds four MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -27,8 +28,10 @@ struct GemmArgs {
   int act;
   int k_chunk;
   int atomic;
+  float* slab;      // TN split-K: partial tiles are stored to slab[z][M][N] (plain stores) and summed by a second kernel
   int vecA, vecB;
   int mt, nt;
+  int xcd_map;      // 1: XCD-aware panel map (many row panels); 0: plain map (few tiles, split-K spreads the XCDs)
 };
 
 #define BK 32
@@ -137,13 +140,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // XCD-aware tile order: the nt column tiles of one row panel run on the same XCD (block ids b and b+8 share an
   // XCD) so that the gathered A rows are fetched into one L2 only. Speed only; any mapping is correct.
   int mt_i, nt_i;
-  {
+  if (g.xcd_map) {
     const int b = blockIdx.x;
     const int x = b & 7, j = b >> 3;
     const int cnt = (g.mt - x + 7) >> 3;           // panels owned by this XCD group
     if (j >= cnt * g.nt) return;
     mt_i = x + 8 * (j / g.nt);
     nt_i = j % g.nt;
+  } else {
+    mt_i = blockIdx.x / g.nt;
+    nt_i = blockIdx.x % g.nt;
   }
   const int m0 = mt_i * BM, n0 = nt_i * BN;
   const int t = threadIdx.x;
@@ -226,7 +232,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int gn = n0 + (wn * NI + j) * 32 + l31;
         if (gn >= g.N) continue;
         float v = acc[i][j][r];
-        if (g.atomic) {
+        if (g.slab) {
+          g.slab[((long)blockIdx.z * g.M + gm) * g.N + gn] = v;
+        } else if (g.atomic) {
           if (g.bias && blockIdx.z == 0) v += g.bias[gn];
           atomicAdd(&g.C[crow + gn], v);
         } else {
@@ -238,13 +246,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// out[m][n] = sum_z slab[z][m][n]  (fixed summation order: bitwise reproducible, unlike float atomics)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long ldc, int M, int N, int splits) {
+  const long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  const long total = (long)M * N;
+  if (e >= total) return;
+  if ((N & 3) == 0) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + z * total + e);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long m = e / N, n = e - m * N;
+    float* o = C + m * ldc + n;
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+  } else {
+    for (long q = e; q < e + 4 && q < total; ++q) {
+      float acc = 0.f;
+      for (int z = 0; z < splits; ++z) acc += slab[z * total + q];
+      C[(q / N) * ldc + (q % N)] = acc;
+    }
+  }
+}
+
 template <int WM, int WN, int MI, int NI, bool A_KM, bool B_KN>
 static int launch(GemmArgs& g, int splits, hipStream_t s) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   g.mt = sbr_cdiv(g.M, BM);
   g.nt = sbr_cdiv(g.N, BN);
+  // With fewer than 64 row panels the XCD-aware map would leave XCDs idle (panel p lives on XCD p % 8): use the plain map,
+  // block ids then rotate over the XCDs through the split-K dimension.
+  g.xcd_map = g.mt >= 64;
   const int per_xcd = sbr_cdiv(g.mt, 8) * g.nt;
-  dim3 grid(per_xcd * 8, 1, splits);
+  dim3 grid(g.xcd_map ? per_xcd * 8 : g.mt * g.nt, 1, splits);
   gemm_f32_kernel<WM, WN, MI, NI, A_KM, B_KN><<<grid, 256, 0, s>>>(g);
   SBR_CHECK_LAUNCH("sbr_gemm_f32");
   return SBR_OK;
@@ -267,6 +301,7 @@ extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx
   g.C = C; g.ldc = ldc; g.c_idx = c_idx; g.M = M; g.N = N; g.K = K; g.act = act;
   g.vecA = aligned16(A, lda); g.vecB = aligned16(B, ldb);
   g.atomic = accumulate_atomic;
+  g.slab = nullptr;
   g.k_chunk = ((K + BK - 1) / BK) * BK;
   if (g.k_chunk == 0) g.k_chunk = BK;
   int splits = 1;
@@ -289,4 +324,43 @@ extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx
   }
   if (N <= 64) return launch<4, 1, 1, 2, false, false>(g, 1, s);
   return launch<2, 2, 2, 2, false, false>(g, 1, s);
+}
+
+// ---- TN with a split-K slab reducer ------------------------------------------------------------------------------------
+static int tn_splits(int M, int N, int K) {
+  const int tiles = sbr_cdiv(M, 64) * sbr_cdiv(N, 128);
+  int want = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU
+  const int max_splits = sbr_cdiv(K, 4 * BK);         // at least 4 slabs of K per workgroup
+  int splits = want < max_splits ? want : max_splits;
+  if (getenv("SBR_TN_SPLITS") && atoi(getenv("SBR_TN_SPLITS")) > 0) splits = atoi(getenv("SBR_TN_SPLITS"));   // tuning aid
+  return splits < 1 ? 1 : splits;
+}
+
+extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
+  return (long)tn_splits(M, N, K) * M * N * (long)sizeof(float);
+}
+
+// C[m, n] = sum_k A[ak(k), m] * B[bk(k), n]  (C is overwritten). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes.
+extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx,
+                               float* C, long ldc, int M, int N, int K, void* workspace, long workspace_bytes, void* stream) {
+  SBR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sbr_gemm_tn_f32: negative size");
+  if (M == 0 || N == 0) return SBR_OK;
+  SBR_REQUIRE(A && B && C, "sbr_gemm_tn_f32: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  int splits = tn_splits(M, N, K);
+  SBR_REQUIRE(workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float), "sbr_gemm_tn_f32: workspace too small");
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.bias = nullptr;
+  g.C = C; g.ldc = ldc; g.c_idx = nullptr; g.M = M; g.N = N; g.K = K; g.act = SBR_ACT_NONE;
+  g.vecA = aligned16(A, lda); g.vecB = aligned16(B, ldb);
+  g.atomic = 0;
+  g.slab = (float*)workspace;
+  g.k_chunk = sbr_cdiv(sbr_cdiv(K > 0 ? K : 1, splits), BK) * BK;
+  splits = K > 0 ? sbr_cdiv(K, g.k_chunk) : 1;
+  int rc = launch<2, 2, 1, 2, true, true>(g, splits, s);
+  if (rc) return rc;
+  const long total = (long)M * N;
+  splitk_reduce_kernel<<<sbr_cdiv(sbr_cdiv(total, 4), 256), 256, 0, s>>>(g.slab, C, ldc, M, N, splits);
+  SBR_CHECK_LAUNCH("sbr_gemm_tn_f32/reduce");
+  return SBR_OK;
 }

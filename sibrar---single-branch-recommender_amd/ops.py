@@ -94,12 +94,18 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None):
 
 
 def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None):
-    """sum_r dz[ai(r)]^T x[bi(r)] -> [dz.shape[1], x.shape[1]]."""
+    """sum_r dz[ai(r)]^T x[bi(r)] -> [dz.shape[1], x.shape[1]] (split-K over r with a deterministic slab reducer)."""
+    from ._lib import lib
     R = n_rows if n_rows is not None else dz.shape[0]
     M, N = dz.shape[1], x.shape[1]
-    out = torch.zeros(M, N, device=dz.device, dtype=torch.float32)
-    if R > 0:
-        gemm(2, dz, dz.stride(0), a_idx, x, x.stride(0), b_idx, None, out, out.stride(0), None, M, N, R, 0, 1)
+    out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
+    if R == 0:
+        return out.zero_()
+    ws_bytes = lib().sbr_gemm_tn_f32_workspace(M, N, R)
+    ws = torch.empty(ws_bytes // 4, device=dz.device, dtype=torch.float32)
+    _timed(('gemm_f32', 2, M, N, R, a_idx is not None or b_idx is not None),
+           lambda: call('sbr_gemm_tn_f32', ptr(dz), dz.stride(0), ptr(a_idx), ptr(x), x.stride(0), ptr(b_idx), ptr(out),
+                        out.stride(0), M, N, R, ptr(ws), ws_bytes, stream()))
     return out
 
 
