@@ -63,8 +63,7 @@ class _Conf:
 
 def run_steps(S, trainer, loader_iter, n, world):
     for _ in range(n):
-        u, i, l = next(loader_iter)
-        trainer.train_step(u, i, l)
+        trainer.train_step(*next(loader_iter))
 
 
 def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_kernels):
@@ -74,7 +73,7 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     trainer = S.Trainer(net, None, None, loss, _Conf(device))
     net.train()
     loader = S.NegativeSamplingDataLoader(ds, batch_size=batch * world, shuffle=True, rank=rank, world=world, device=device,
-                                          prefetch=4)
+                                          prefetch=4, draw_fn=trainer.fused.draw if trainer.fused is not None else None)
     it = iter(loader)
     run_steps(S, trainer, it, warmup, world)
     S.ops.KernelTimer.reset(time_kernels)

@@ -16,6 +16,7 @@ from .losses import (InfoNCE, RecBayesianPersonalizedRankingLoss, RecBinaryCross
                      RecSampledSoftmaxLoss, RecommenderSystemLoss, RecommenderSystemLossesEnum)
 from .optim import FlatParameters, FusedOptimizer                                           # noqa: F401
 from .trainer import Trainer                                                                # noqa: F401
+from .engine import FusedTrainStep                                                          # noqa: F401
 from .evaluation import FullEvaluator, evaluate_recommender_algorithm                       # noqa: F401
 from .datasets import NegativeSamplingDataLoader, SyntheticDataset                          # noqa: F401
 from . import ops, parallel, sampling                                                       # noqa: F401

@@ -74,9 +74,16 @@ def check(status: int):
         raise SibrarHipError(lib().sbr_last_error().decode())
 
 
+_FN = {}
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise SibrarHipError on a non-zero status."""
-    check(getattr(lib(), name)(*args))
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    if fn(*args) != 0:
+        raise SibrarHipError(lib().sbr_last_error().decode())
 
 
 def ptr(t):
@@ -84,6 +91,26 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_STREAM = [None]
+
+
 def stream():
+    """hipStream_t of torch's current stream. ``pin_stream`` caches it for the duration of a fused step."""
+    if _STREAM[0] is not None:
+        return _STREAM[0]
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+class pin_stream:
+    """Context manager: resolve torch's current stream once and reuse the handle for every kernel call inside."""
+
+    def __enter__(self):
+        import torch
+        self.prev = _STREAM[0]
+        _STREAM[0] = torch.cuda.current_stream().cuda_stream
+        return _STREAM[0]
+
+    def __exit__(self, *exc):
+        _STREAM[0] = self.prev
+        return False

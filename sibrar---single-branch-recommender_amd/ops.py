@@ -93,26 +93,45 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None):
     return out
 
 
-def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None):
+_TN_WS = {}
+
+
+def _tn_workspace(device, nbytes):
+    """Grow-only scratch for the split-K slabs (one per device; reused by every dW product of a step)."""
+    ws = _TN_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4, 1 << 20), device=device, dtype=torch.float32)
+        _TN_WS[device] = ws
+    return ws
+
+
+def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None, out=None):
     """sum_r dz[ai(r)]^T x[bi(r)] -> [dz.shape[1], x.shape[1]] (split-K over r with a deterministic slab reducer)."""
     from ._lib import lib
     R = n_rows if n_rows is not None else dz.shape[0]
     M, N = dz.shape[1], x.shape[1]
-    out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
     if R == 0:
         return out.zero_()
     ws_bytes = lib().sbr_gemm_tn_f32_workspace(M, N, R)
-    ws = torch.empty(ws_bytes // 4, device=dz.device, dtype=torch.float32)
+    ws = _tn_workspace(dz.device, ws_bytes)
     _timed(('gemm_f32', 2, M, N, R, a_idx is not None or b_idx is not None),
            lambda: call('sbr_gemm_tn_f32', ptr(dz), dz.stride(0), ptr(a_idx), ptr(x), x.stride(0), ptr(b_idx), ptr(out),
-                        out.stride(0), M, N, R, ptr(ws), ws_bytes, stream()))
+                        out.stride(0), M, N, R, ptr(ws), ws.numel() * 4, stream()))
     return out
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+_COLSUM_WS = {}
+
+
+def colsum(x: torch.Tensor, out=None) -> torch.Tensor:
     n, C = x.shape
-    out = torch.empty(C, device=x.device, dtype=torch.float32)
-    ws = torch.empty(C, device=x.device, dtype=torch.float64)
+    if out is None:
+        out = torch.empty(C, device=x.device, dtype=torch.float32)
+    ws = _COLSUM_WS.get((x.device, C))
+    if ws is None:
+        ws = _COLSUM_WS[(x.device, C)] = torch.empty(C, device=x.device, dtype=torch.float64)
     call('sbr_colsum', ptr(x), x.stride(0), n, C, ptr(out), ptr(ws), stream())
     return out
 

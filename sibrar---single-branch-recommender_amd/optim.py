@@ -88,6 +88,10 @@ class FusedOptimizer:
 
     def step(self):
         self._sync_grads()
+        self.step_flat()
+
+    def step_flat(self):
+        """Update from the flat gradient buffer as it is (the fused step writes gradients there directly)."""
         self.step_count += 1
         fp = self.fp
         if self.name == 'adagrad':

@@ -280,34 +280,42 @@ class FeatureEmbedding(nn.Module):
             h = dst
         return hidden
 
-    def front_backward(self, p, hidden, rows, n, out, dout, slots):
+    def front_backward(self, p, hidden, rows, n, out, dout, slots, grad_out=None):
+        """Gradients of this modality's parameters. ``grad_out`` (optional): tensors to write into instead of fresh ones —
+        lookup-table gradients are ACCUMULATED into them (they must be zero-initialised), dense ones are overwritten."""
         t = self._table
         st = stream()
         if self.kind == 'categorical':
-            dW = torch.zeros_like(p[0])
+            dW = torch.zeros_like(p[0]) if grad_out is None else grad_out[0]
             call('sbr_scatter_add_rows', ptr(dout), dout.stride(0), ptr(slots), ptr(rows), ptr(dW), dW.stride(0), n,
                  dout.shape[1], st)
             return [dW]
         if self.kind == 'tag':
-            dW = torch.zeros_like(p[0])
+            dW = torch.zeros_like(p[0]) if grad_out is None else grad_out[0]
             call('sbr_bag_mean_bwd', ptr(dout), dout.stride(0), ptr(slots), ptr(t.tags), t.T, t.pad, ptr(rows), ptr(dW),
                  dW.stride(0), n, dout.shape[1], st)
             return [dW]
         L = len(p) // 2
         grads = [None] * (2 * L)
+        go = grad_out if grad_out is not None else [None] * (2 * L)
         dz = ops.act_grad(dout, out, self._act, idx=slots, n_rows=n)           # [n, C] compact
         for l in range(L - 1, -1, -1):
             W = p[2 * l]
-            grads[2 * l + 1] = ops.colsum(dz)
+            grads[2 * l + 1] = ops.colsum(dz, out=go[2 * l + 1])
             if l == 0 and self.kind == 'csr':
-                dWt = torch.zeros(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
+                # the projector weight is column-major: its gradient is accumulated in the same [n_cols, C] layout
+                if go[0] is not None:
+                    dWt = go[0].t()
+                    assert dWt.is_contiguous()
+                else:
+                    dWt = torch.zeros(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
                 call('sbr_csr_project_bwd', ptr(t.indptr), ptr(t.indices), ptr(t.data), ptr(dz), dz.stride(0), ptr(rows),
                      ptr(dWt), dWt.stride(0), n, W.shape[0], st)
                 grads[0] = dWt.t()
             elif l == 0:
-                grads[0] = ops.matmul_tn(dz, t.values, b_idx=rows, n_rows=n)
+                grads[0] = ops.matmul_tn(dz, t.values, b_idx=rows, n_rows=n, out=go[0])
             else:
-                grads[2 * l] = ops.matmul_tn(dz, hidden[l - 1], n_rows=n)
+                grads[2 * l] = ops.matmul_tn(dz, hidden[l - 1], n_rows=n, out=go[2 * l])
                 dh = ops.matmul_nn(dz, W if W.stride(1) == 1 else W.contiguous())
                 dz = ops.act_grad(dh, hidden[l - 1], self._act)
         return grads

@@ -51,6 +51,17 @@ class Trainer:
         self.batch_verbose = _get(_get(conf, 'run_settings'), 'batch_verbose', False)
         self.scorer = _get(conf, 'scorer', 'fp32')
         self.best_value = self.best_metrics = self.best_epoch = None
+        # the fused launch choreography (engine.FusedTrainStep) replaces autograd when the model is a SingleBranchNet with
+        # an entity item side; `conf.fused_step = False` keeps the autograd path (same kernels, same results)
+        self.fused = None
+        if _get(conf, 'fused_step', True):
+            try:
+                from .engine import FusedTrainStep
+                from .sbnet import SingleBranchNet
+                if isinstance(model, SingleBranchNet):
+                    self.fused = FusedTrainStep(model, rec_loss, self.optimizer)
+            except NotImplementedError:
+                self.fused = None
         logging.info(f'Built Trainer module - optimizer: {self.optimizer.name} lr: {self.lr} wd: {self.wd}')
 
     def fit(self):
@@ -90,8 +101,11 @@ class Trainer:
     def train(self):
         return self._train()
 
-    def train_step(self, u_idxs, i_idxs, labels):
+    def train_step(self, u_idxs, i_idxs, labels, draws=None):
         """trainer.py:205-223 for one batch; returns the device-side loss tensors (no host sync)."""
+        if self.fused is not None:
+            total, rec, reg = self.fused.step(u_idxs, i_idxs, labels, draws)
+            return total, rec, {'reg_loss': reg}
         u_idxs = u_idxs.to(self.device, non_blocking=True)
         i_idxs = i_idxs.to(self.device, non_blocking=True)
         labels = labels.to(self.device, non_blocking=True)
@@ -111,8 +125,8 @@ class Trainer:
         self.model.train()
         sums = {}
         n_batches = len(self.train_loader)
-        for batch_count, (u_idxs, i_idxs, labels) in enumerate(self.train_loader):
-            total, rec, regs = self.train_step(u_idxs, i_idxs, labels)
+        for batch_count, batch in enumerate(self.train_loader):
+            total, rec, regs = self.train_step(*batch)
             vals = {'loss': total, 'rec_loss': rec, **regs}
             for k, v in vals.items():
                 v = v.double().sum()

@@ -239,3 +239,37 @@ def test_g11_sgd_baseline():
     close(m.predict(u, i).cpu(), z['logits'], what='logits', **TOL)
     m.train()
     close(m(u, i).detach().cpu(), z['logits'], what='logits(train)', **TOL)
+
+
+@pytest.mark.parametrize('user_kind,loss_name', [('lookup', 'bpr'), ('entity', 'ssm_uniform'), ('linear', 'bce')])
+def test_fused_step_matches_autograd_path(user_kind, loss_name):
+    """engine.FusedTrainStep (hand-written backward, no autograd) == module path (autograd over the same kernels): same
+    losses and the same parameters after three AdamW steps on the golden world."""
+    import sibrar_amd as S
+    z = load('g4_full_net')
+    case = [c for c in MANIFEST['g4_full_net']['cases'] if c['name'] == f'{user_kind}_bpr'][0]
+    nets = [product_net(z, case, f"{case['name']}/sd0/") for _ in range(2)]
+    for n_ in nets:
+        n_.train()
+    opts = [S.FusedOptimizer(n_, 'adamw', lr=1e-2, weight_decay=1e-2) for n_ in nets]
+    fused = S.FusedTrainStep(nets[1], _loss(loss_name), opts[1])
+    rng = np.random.default_rng(5)
+    for s_ in range(3):
+        u = torch.from_numpy(rng.integers(0, U, size=6))
+        i = torch.from_numpy(rng.integers(0, I, size=(6, 4)))
+        labels = torch.zeros(6, 4, dtype=torch.float64)
+        labels[:, 0] = 1
+        logits = nets[0](u.to(DEV), i.to(DEV))
+        loss = _loss(loss_name).compute_loss(logits, labels.to(DEV))
+        reg = nets[0].get_and_reset_other_loss()['reg_loss']
+        (loss + reg).backward()
+        opts[0].step()
+        opts[0].zero_grad()
+        total, rec, reg2 = fused.step(u, i, labels)
+        close(rec.cpu(), loss.detach().cpu().double(), what=f'rec loss step {s_}', rtol=1e-5, atol=1e-7)
+        close(reg2.cpu().reshape(-1), reg.detach().cpu().double().reshape(-1), what=f'reg loss step {s_}', rtol=1e-5, atol=1e-7)
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    skip = bn_shadowed_biases(sd0.keys())
+    for k in sd0:
+        if k not in skip:
+            close(sd1[k].cpu(), sd0[k].cpu(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-5)
