@@ -246,26 +246,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// out[m][n] = sum_z slab[z][m][n]  (fixed summation order: bitwise reproducible, unlike float atomics)
+// out[m][n] = sum_z slab[z][m][n] in a fixed order (bitwise reproducible, unlike float atomics).
+// 256 threads = 32 consecutive output elements x 8 z-groups; z-group g sums z = g, g+8, ... and the eight partial sums are
+// combined through LDS in group order. One workgroup per 32 outputs keeps >= 512 workgroups busy even for a 128x128 dW.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long ldc, int M, int N, int splits) {
-  const long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  __shared__ float part[8][32];
+  const int e_local = threadIdx.x & 31, zg = threadIdx.x >> 5;
   const long total = (long)M * N;
-  if (e >= total) return;
-  if ((N & 3) == 0) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < splits; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + z * total + e);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const long m = e / N, n = e - m * N;
-    float* o = C + m * ldc + n;
-    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
-  } else {
-    for (long q = e; q < e + 4 && q < total; ++q) {
-      float acc = 0.f;
-      for (int z = 0; z < splits; ++z) acc += slab[z * total + q];
-      C[(q / N) * ldc + (q % N)] = acc;
-    }
+  const long e = blockIdx.x * 32L + e_local;
+  float acc = 0.f;
+  if (e < total)
+    for (int z = zg; z < splits; z += 8) acc += slab[z * total + e];
+  part[zg][e_local] = acc;
+  __syncthreads();
+  if (zg == 0 && e < total) {
+    float v = part[0][e_local];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) v += part[g][e_local];
+    C[(e / N) * ldc + (e % N)] = v;
   }
 }
 
@@ -360,7 +358,7 @@ extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const
   int rc = launch<2, 2, 1, 2, true, true>(g, splits, s);
   if (rc) return rc;
   const long total = (long)M * N;
-  splitk_reduce_kernel<<<sbr_cdiv(sbr_cdiv(total, 4), 256), 256, 0, s>>>(g.slab, C, ldc, M, N, splits);
+  splitk_reduce_kernel<<<sbr_cdiv(total, 32), 256, 0, s>>>(g.slab, C, ldc, M, N, splits);
   SBR_CHECK_LAUNCH("sbr_gemm_tn_f32/reduce");
   return SBR_OK;
 }
