@@ -26,7 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
-#define ST_TILE 64                       // items per LDS tile
 #define ST_WAVES 7                       // consumer waves
 #define ST_ROWS (ST_WAVES * 32)          // users per workgroup
 #define ST_THREADS ((ST_WAVES + 1) * 64) // + loader wave
@@ -126,12 +125,13 @@ __device__ __forceinline__ int st_peek(lds_int* p) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots; DBG: timing-only ablation builds
+template <int KS, int NS, int ST_TILE, int DBG>   // KS = D / 16; NS = LDS ring slots; ST_TILE = items per LDS tile (32 | 64); DBG: ablations
 __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int cap,
     float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
+  constexpr int NJ = ST_TILE / 32;                         // 32-column accumulator tiles per item tile
   constexpr int ROWB = D * 2;                              // bytes per item row
   constexpr int TILEB = ST_TILE * ROWB;                    // bytes per LDS tile
   constexpr int CPR = D / 8;                               // 16-byte chunks per item row
@@ -245,13 +245,16 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
     const unsigned char* cur = smem + slot * TILEB;
 
-    f32x16 acc[2];
+    f32x16 acc[2];     // NJ of them are used (a template-dependent array bound makes hipcc drop the kernel's host stub)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nj][r] = 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
+      for (int nj = 0; nj < NJ; ++nj) {
         const int i = nj * 32 + l31;                       // item row within the tile
         const int c = 2 * s + half;                        // 16-byte chunk: k = 16 s + 8 half .. +7
         const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
       }
     }
     // the tile's LDS reads have been consumed by the MFMAs above: hand the slot back to the loader
-    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0]), "v"(acc[1]) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0]), "v"(acc[NJ - 1]) : "memory");
     if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);
 
     // exclusions of this tile (eval.py:219-220): an excluded (row, column) pair is delivered as ONE bit to the lane that
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
       }
       e_pending = true;
     }
-    if constexpr (DBG == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
+    if constexpr (DBG == 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[NJ - 1])); continue; }
     // epilogue: threshold filter. Per 32x32 accumulator tile: 16 v_cmp whose ballots stay in SGPRs, OR-reduced to one branch.
     // Survivors are appended to their row's buffer at positions derived from the ballot (v_mbcnt prefix count; no LDS
     // atomics, no round trip: the append is a fire-and-forget ds_write).
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
     unsigned int ex = 0u;
     bool ex_loaded = false;
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
+    for (int nj = 0; nj < NJ; ++nj) {
       unsigned long long br[16];
       unsigned long long any = 0;
 #pragma unroll
@@ -387,7 +390,7 @@ static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64
 
 extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
 
-template <int KS, int NS>
+template <int KS, int NS, int ST_TILE>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, void* dbg_buf, hipStream_t s) {
   const int cap = st_cap(k);
@@ -396,8 +399,8 @@ static int st_launch(const void* U, const void* It, long Bu, int I, const long* 
   // SBR_ST_DEBUG=1|2 selects timing-only ablation builds (1: MFMA main loop only, 2: + threshold compares; results are
   // meaningless), 4 adds per-wave cycle stamps written to `workspace`. Unset / 0 = the real kernel.
   const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;
-  auto kern = dbg == 1 ? score_topk_f16_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_kernel<KS, NS, 2> :
-              (dbg == 4 ? score_topk_f16_kernel<KS, NS, 4> : score_topk_f16_kernel<KS, NS, 0>));
+  auto kern = dbg == 1 ? score_topk_f16_kernel<KS, NS, ST_TILE, 1> : (dbg == 2 ? score_topk_f16_kernel<KS, NS, ST_TILE, 2> :
+              (dbg == 4 ? score_topk_f16_kernel<KS, NS, ST_TILE, 4> : score_topk_f16_kernel<KS, NS, ST_TILE, 0>));
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
@@ -419,9 +422,9 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 64: return st_launch<4, 6>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    case 128: return st_launch<8, 5>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    case 256: return st_launch<16, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 64: return st_launch<4, 6, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 128: return st_launch<8, 5, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
+    case 256: return st_launch<16, 2, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
       return SBR_ERR_ARG;
