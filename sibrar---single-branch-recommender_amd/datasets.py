@@ -101,12 +101,14 @@ class NegativeSamplingDataLoader:
 
     def __init__(self, dataset, batch_size: int = 256, shuffle: bool = True, strategy: Optional[str] = None,
                  rank: int = 0, world: int = 1, max_batches: Optional[int] = None, device=None, prefetch: int = 0,
-                 draw_fn=None):
+                 draw_fn=None, prepare_fn=None):
         """``device``: run the collision test of the collate on that GPU (DevicePositiveIndex) instead of numpy.
         ``prefetch`` > 0: a producer thread prepares up to that many batches ahead (single producer, so the RNG streams are
         consumed in the same order as without it).
         ``draw_fn(u_shape, i_shape)``: optional callable (engine.FusedTrainStep.draw) evaluated by the producer for every
-        batch; its result is yielded as a 4th element so that the modality draw also leaves the launch thread."""
+        batch; its result is yielded as a 4th element so that the modality draw also leaves the launch thread.
+        ``prepare_fn(u, i, labels)``: same, but with the batch itself (engine.FusedTrainStep.prepare: draw + launch plan +
+        uploads on a side stream) — the 4th element is then a ready ``PreparedBatch``."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.strategy = strategy or dataset.negative_sampling_strategy
         if self.strategy not in ('uniform_recbole', 'uniform'):
@@ -119,6 +121,7 @@ class NegativeSamplingDataLoader:
         self.rank, self.world, self.max_batches = rank, world, max_batches
         self.prefetch = prefetch
         self.draw_fn = draw_fn
+        self.prepare_fn = prepare_fn
 
     def __len__(self):
         n = (len(self.rows) + self.batch_size - 1) // self.batch_size
@@ -166,7 +169,10 @@ class NegativeSamplingDataLoader:
             # data parallel: every rank consumes the same global streams and keeps its slice (parallel.shard_batch)
             if self.world > 1:
                 u, i, l = u[self.rank::self.world], i[self.rank::self.world], l[self.rank::self.world]
-            if self.draw_fn is not None:
+            if self.prepare_fn is not None:
+                tu, ti, tl = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)
+                yield tu, ti, tl, self.prepare_fn(tu, ti, tl)
+            elif self.draw_fn is not None:
                 yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), self.draw_fn(u.shape, i.shape)
             else:
                 yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)

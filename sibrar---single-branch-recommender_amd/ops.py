@@ -84,11 +84,12 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
     return out
 
 
-def matmul_nn(dz, W, a_idx=None, n_rows=None):
+def matmul_nn(dz, W, a_idx=None, n_rows=None, out=None):
     """dz[ai(m)] @ W, W: [K, N] row-major."""
     M = n_rows if n_rows is not None else (a_idx.numel() if a_idx is not None else dz.shape[0])
     K, N = W.shape
-    out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
     gemm(1, dz, dz.stride(0), a_idx, W, W.stride(0), None, None, out, out.stride(0), None, M, N, K, 0, 0)
     return out
 

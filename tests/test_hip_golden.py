@@ -273,3 +273,49 @@ def test_fused_step_matches_autograd_path(user_kind, loss_name):
     for k in sd0:
         if k not in skip:
             close(sd1[k].cpu(), sd0[k].cpu(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_step_graph_replay_equals_plain_launches():
+    """hipGraph replay of forward+backward (engine.FusedTrainStep, use_graph=True) == the same launches issued one by one:
+    same losses and parameters after 12 AdamW steps on a small c2-shaped world (text modality + item-id embedding, both
+    one of them drawn per index, so the per-modality row counts vary from step to step and the plans are padded to a
+    bucket; a signature is captured at its second sighting)."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
+    cfg = {'shared_common_dim': 32, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [32], 'preference_hidden_layers': [], 'common_modality_dim': 32}}
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+        net.train()
+        opt = S.FusedOptimizer(net, 'adamw', lr=1e-2, weight_decay=1e-2)
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+        fused = S.FusedTrainStep(net, loss, opt, use_graph=use_graph)
+        rng = np.random.default_rng(9)
+        losses = []
+        for s_ in range(12):
+            B = 64 if s_ != 4 else 48                     # one ragged batch in between (its own signature, plain launches)
+            u = torch.from_numpy(rng.integers(0, ds.n_users, size=B))
+            i = torch.from_numpy(rng.integers(0, ds.n_items, size=(B, 4)))
+            labels = torch.zeros(B, 4, dtype=torch.float64)
+            labels[:, 0] = 1
+            losses.append(torch.stack(fused.step(u, i, labels)).cpu())
+        runs.append((fused, losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    assert runs[0][0].n_replays == 0
+    assert runs[1][0].n_replays >= 4                        # 64 x 4 = 256 draws, bucket 64: at most 2-3 signatures
+    for s_, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
+        close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
+    # zero-gradient parameters (Adam turns their rounding noise into +-lr steps): biases in front of a BatchNorm, and the
+    # trailing BatchNorm's shift — the softmax gradient sums to zero over each user's candidates, so a common shift of all
+    # item representations has no gradient
+    skip = set(bn_shadowed_biases(runs[0][2].keys())) | {'item_embedding_module.sb_net.1.bias'}
+    for k in runs[0][2]:
+        if k in skip:
+            continue
+        # not bit-equal: split-K chunking follows the (padded) row counts and the table gradients use float atomics; AdamW at
+        # lr 1e-2 turns that rounding noise into ~1e-6 absolute differences on near-zero gradients
+        close(runs[1][2][k].double(), runs[0][2][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
