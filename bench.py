@@ -31,6 +31,7 @@ import torch
 PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_MFMA_F16 = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM = 8000.0         # GB/s
+SETTLE = 30               # extra untimed steps after --warmup (see bench_training)
 
 C2 = dict(n_users=100_000, n_items=50_000, nnz=5_000_000, feat_dim=768, emb_dim=128, n_neg=10)
 
@@ -61,6 +62,12 @@ class _Conf:
         self.train_eval = None
 
 
+def epochs(loader):
+    """Batches of consecutive epochs (a long --steps run crosses the epoch boundary like Trainer.fit does)."""
+    while True:
+        yield from loader
+
+
 def run_steps(S, trainer, loader_iter, n, world):
     for _ in range(n):
         trainer.train_step(*next(loader_iter))
@@ -72,10 +79,17 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
                                    neg_train=ds.n_negative_samples)
     trainer = S.Trainer(net, None, None, loss, _Conf(device))
     net.train()
-    loader = S.NegativeSamplingDataLoader(ds, batch_size=batch * world, shuffle=True, rank=rank, world=world, device=device,
+    # weak scaling: every rank collates its own per-GPU batch (dp_sampling='local': contiguous slice of the shared epoch order,
+    # rank-seeded negative stream) — the bit-exact 'global' mode makes every rank draw the whole global batch on its host
+    np.random.seed(42 + rank)
+    loader = S.NegativeSamplingDataLoader(ds, batch_size=batch, shuffle=True, rank=rank, world=world, device=device,
+                                          dp_sampling='local',
                                           prefetch=4, prepare_fn=trainer.fused.prepare if trainer.fused is not None else None)
-    it = iter(loader)
-    run_steps(S, trainer, it, warmup, world)
+    it = epochs(loader)
+    # W warm-up steps (graph capture, allocator), then SETTLE more untimed steps: the loader's two pipeline stages run up to
+    # 2 * prefetch + 2 batches ahead while the first steps compile / capture, and a timed region that starts on that head start
+    # would report the consumer's burst rate instead of the sustained rate of the whole pipeline.
+    run_steps(S, trainer, it, warmup + SETTLE, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -94,6 +108,7 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
         run_steps(S, trainer, it, steps, world)
         timings = S.ops.KernelTimer.results()
         S.ops.KernelTimer.reset(False)
+    loader.close()
     if trainer.fused is not None:
         trainer.fused.close()
     if world > 1:
@@ -209,7 +224,7 @@ def cpu_baseline(S, ds, net, batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch-size', type=int, default=8192, help='per-GPU batch (positive interactions per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -219,6 +234,9 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
+    # three Python threads hand batches to each other (collate -> prepare -> launch): with CPython's default 5 ms switch
+    # interval a waiting thread can sit behind the GIL for longer than a whole B=256 step
+    sys.setswitchinterval(float(os.environ.get('SBR_SWITCH_INTERVAL', '1e-3')))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -246,7 +264,7 @@ def main():
                                'sampled-softmax, 10 negatives, AdamW; user = embedding lookup, item = SingleBranchNet entity '
                                '(text 768-d + item-id embedding, hidden [128], BatchNorm)' + (' [SMALL DEBUG SIZE]' if args.small else ''),
                    'batch_per_gpu': args.batch_size, 'global_batch': args.batch_size * world, 'n_negatives': cfg['n_neg'],
-                   'parallelism': f'dp{world}' if world > 1 else 'single'},
+                   'parallelism': f'dp{world}' if world > 1 else 'single', 'settle_steps': SETTLE},
     }
     roof = dominant_gemm(timings, args.steps) if rank == 0 else None
     if roof:

@@ -9,6 +9,8 @@
 """
 from __future__ import annotations
 
+import atexit
+import weakref
 from types import SimpleNamespace
 from typing import Dict, Optional, Sequence
 
@@ -17,7 +19,7 @@ import scipy.sparse as sp
 import torch
 
 from .features import HostFeature
-from .sampling import (DevicePositiveIndex, PositiveIndex, loader_epoch_order, recbole_negative_collate,
+from .sampling import (DevicePositiveIndex, PositiveIndex, is_arange, loader_epoch_order, recbole_negative_collate,
                        uniform_negative_collate)
 
 
@@ -96,17 +98,31 @@ class SyntheticDataset:
                                user_features=self.user_features, item_features=self.item_features)
 
 
+_LIVE_LOADERS = weakref.WeakSet()
+
+
+@atexit.register
+def _close_loaders():
+    for ld in list(_LIVE_LOADERS):
+        ld.close()
+
+
 class NegativeSamplingDataLoader:
     """Default training loader of the reference (data/dataloader.py:134-198 + shuffle) with the vectorised collate."""
 
     def __init__(self, dataset, batch_size: int = 256, shuffle: bool = True, strategy: Optional[str] = None,
                  rank: int = 0, world: int = 1, max_batches: Optional[int] = None, device=None, prefetch: int = 0,
-                 draw_fn=None, prepare_fn=None):
+                 draw_fn=None, prepare_fn=None, dp_sampling: str = 'global'):
         """``device``: run the collision test of the collate on that GPU (DevicePositiveIndex) instead of numpy.
         ``prefetch`` > 0: a producer thread prepares up to that many batches ahead (single producer, so the RNG streams are
         consumed in the same order as without it).
         ``draw_fn(u_shape, i_shape)``: optional callable (engine.FusedTrainStep.draw) evaluated by the producer for every
         batch; its result is yielded as a 4th element so that the modality draw also leaves the launch thread.
+        ``dp_sampling`` (world > 1): 'global' — ``batch_size`` is the GLOBAL batch; every rank draws the whole global batch
+        from the same random streams and keeps rows rank::world, so the union over ranks is bit-identical to the 1-GPU
+        batch (host cost grows with world). 'local' — ``batch_size`` is the PER-RANK batch; a rank collates only its own
+        contiguous slice of the shared epoch order and draws negatives from its own global-numpy stream (seed it per rank):
+        host cost independent of world, the weak-scaling mode of bench.py.
         ``prepare_fn(u, i, labels)``: same, but with the batch itself (engine.FusedTrainStep.prepare: draw + launch plan +
         uploads on a side stream) — the 4th element is then a ready ``PreparedBatch``."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
@@ -119,12 +135,20 @@ class NegativeSamplingDataLoader:
         self.positives = (DevicePositiveIndex(dataset.user_sampling_matrix, device) if device is not None
                           else PositiveIndex(dataset.user_sampling_matrix))
         self.rank, self.world, self.max_batches = rank, world, max_batches
+        if dp_sampling not in ('global', 'local'):
+            raise ValueError(f'dp_sampling {dp_sampling!r}')
+        self.dp_sampling = dp_sampling
         self.prefetch = prefetch
         self.draw_fn = draw_fn
         self.prepare_fn = prepare_fn
+        self._prepare_takes_key = None
+        self._identity_items = is_arange(np.asarray(dataset.items_in_split))
 
     def __len__(self):
-        n = (len(self.rows) + self.batch_size - 1) // self.batch_size
+        if self.dp_sampling == 'local' and self.world > 1:
+            n = len(self.rows) // (self.batch_size * self.world)      # whole global steps only: every rank runs the same count
+        else:
+            n = (len(self.rows) + self.batch_size - 1) // self.batch_size
         return n if self.max_batches is None else min(n, self.max_batches)
 
     def __iter__(self):
@@ -132,46 +156,106 @@ class NegativeSamplingDataLoader:
             return self._produce()
         import queue
         import threading
-        q = queue.Queue(maxsize=self.prefetch)
+        self.close()                                   # one live pipeline per loader
         done = object()
+        stop = threading.Event()
 
-        def worker():
+        def put(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def stage(source, sink, fn):
             try:
-                for b in self._produce():
-                    q.put(b)
-                q.put(done)
+                for b in source:
+                    if stop.is_set() or not put(sink, fn(b)):
+                        return
+                put(sink, done)
             except BaseException as e:      # surface producer errors in the consumer
-                q.put(e)
+                put(sink, e)
 
-        threading.Thread(target=worker, daemon=True).start()
-
-        def consume():
-            while True:
-                b = q.get()
+        def drain(q):
+            while not stop.is_set():
+                try:
+                    b = q.get(timeout=0.05)
+                except queue.Empty:
+                    continue
                 if b is done:
                     return
                 if isinstance(b, BaseException):
                     raise b
                 yield b
-        return consume()
 
-    def _produce(self):
+        out = queue.Queue(maxsize=self.prefetch)
+        threads = []
+        if self.prepare_fn is None:
+            threads.append(threading.Thread(target=stage, args=(self._produce(), out, lambda b: b), daemon=True))
+        else:
+            # two pipeline stages, one thread each: collate (global numpy stream) -> prepare (entity streams, uploads). Each
+            # random stream is still consumed by exactly one thread in batch order.
+            mid = queue.Queue(maxsize=self.prefetch)
+            threads.append(threading.Thread(target=stage, args=(self._produce(prepare=False), mid, lambda b: b), daemon=True))
+            threads.append(threading.Thread(target=stage, args=(drain(mid), out, lambda b: (*b, self._prepare(*b))),
+                                            daemon=True))
+        for th in threads:
+            th.start()
+        self._live = (stop, threads)
+        _LIVE_LOADERS.add(self)
+        return drain(out)
+
+    def _prepare(self, u, i, l):
+        # the collates of this loader always produce "first column positive, the rest negative" labels: tell prepare()
+        # (engine.FusedTrainStep.prepare keeps one device copy per shape) when it understands the promise
+        if self._prepare_takes_key is None:
+            import inspect
+            try:
+                self._prepare_takes_key = 'labels_key' in inspect.signature(self.prepare_fn).parameters
+            except (TypeError, ValueError):
+                self._prepare_takes_key = False
+        if self._prepare_takes_key:
+            return self.prepare_fn(u, i, l, labels_key='first_column_positive')
+        return self.prepare_fn(u, i, l)
+
+    def close(self):
+        """Stop the producer threads of the current iteration (also run at interpreter exit: a thread that is inside a
+        HIP call while Python finalises aborts the process)."""
+        live = getattr(self, '_live', None)
+        if live is None:
+            return
+        stop, threads = live
+        stop.set()
+        for th in threads:
+            th.join(timeout=5.0)
+        self._live = None
+
+    def _produce(self, prepare: bool = True):
         n = len(self.rows)
         order = loader_epoch_order(n) if self.shuffle else np.arange(n)
+        local = self.dp_sampling == 'local' and self.world > 1
         for b in range(len(self)):
-            sel = order[b * self.batch_size:(b + 1) * self.batch_size]
+            if local:       # rank r owns the r-th contiguous chunk of every global step (an incomplete last global step is dropped)
+                lo = (b * self.world + self.rank) * self.batch_size
+                sel = order[lo:lo + self.batch_size]
+            else:
+                sel = order[b * self.batch_size:(b + 1) * self.batch_size]
             if self.strategy == 'uniform_recbole':
                 u, i, l = recbole_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.items_in_split,
-                                                   self.positives)
+                                                   self.positives, self._identity_items)
             else:
                 u, i, l = uniform_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.n_items,
                                                    self.positives)
             # data parallel: every rank consumes the same global streams and keeps its slice (parallel.shard_batch)
-            if self.world > 1:
+            if self.world > 1 and not local:
                 u, i, l = u[self.rank::self.world], i[self.rank::self.world], l[self.rank::self.world]
-            if self.prepare_fn is not None:
+            if not prepare:
+                yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)
+            elif self.prepare_fn is not None:
                 tu, ti, tl = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)
-                yield tu, ti, tl, self.prepare_fn(tu, ti, tl)
+                yield tu, ti, tl, self._prepare(tu, ti, tl)
             elif self.draw_fn is not None:
                 yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), self.draw_fn(u.shape, i.shape)
             else:

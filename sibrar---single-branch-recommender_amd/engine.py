@@ -98,19 +98,23 @@ class _EntityRun:
         pos, order = draw
         flat = pos.reshape(-1)
         R = flat.size
-        order_idx = np.argsort(flat, kind='stable').astype(np.int32)
-        counts = np.bincount(flat, minlength=len(order))
+        # stable counting sort by modality = the slot lists of the modalities one after the other (a handful of modalities:
+        # one compare + flatnonzero pass each beats a general argsort)
+        lists = [np.flatnonzero(flat == m).astype(np.int32) for m in range(len(order))]
+        counts = np.array([l.size for l in lists], dtype=np.int64)
         if pad:
             bucket = 64
             while bucket * bucket < 4 * R:
                 bucket *= 2
             caps = (counts + bucket - 1) // bucket * bucket
-            padded = np.full(int(caps.sum()), R, dtype=np.int32)
-            src = dst = 0
-            for c, cap in zip(counts.tolist(), caps.tolist()):
-                padded[dst:dst + c] = order_idx[src:src + c]
-                src, dst = src + c, dst + cap
-            order_idx, counts = padded, caps
+            order_idx = np.full(int(caps.sum()), R, dtype=np.int32)
+            dst = 0
+            for l, cap in zip(lists, caps.tolist()):
+                order_idx[dst:dst + l.size] = l
+                dst += cap
+            counts = caps
+        else:
+            order_idx = np.concatenate(lists) if lists else np.empty(0, np.int32)
         return order_idx, pos.shape[1], tuple(int(c) for c in counts), tuple(order), R, bool(pad)
 
     def forward(self, idx: torch.Tensor, plan, seed: int, slots: Optional[torch.Tensor] = None):
@@ -308,6 +312,7 @@ class FusedTrainStep:
         self._arena_buf = None
         self.n_replays = 0
         self._up_stream = None
+        self._label_cache = {}
         _LIVE.add(self)
         self.opt.zero_grad()
 
@@ -353,12 +358,15 @@ class FusedTrainStep:
         return rec + reg, rec, reg
 
     # ---- host side of a step: draw, plan, uploads (may run on the loader thread) ---------------------------------------------
-    def prepare(self, u_idxs, i_idxs, labels, draws=None, ahead: bool = True) -> 'PreparedBatch':
+    def prepare(self, u_idxs, i_idxs, labels, draws=None, ahead: bool = True, labels_key=None) -> 'PreparedBatch':
         """Everything of a step that is not a kernel launch: modality draw (entity generators, consumed in step order),
         counting-sort plan, and the upload of indices / labels / slot lists. With ``ahead`` (loader thread) the uploads go
         through pinned staging buffers on a private stream and the step only waits on their event, so the launch thread never
         blocks on PCIe. The index buffers carry one sentinel entry behind them (= their first entry): the entity that the
-        padded launches of a graph-mode plan resolve (``_EntityRun.plan``)."""
+        padded launches of a graph-mode plan resolve (``_EntityRun.plan``).
+        ``labels_key``: a hashable promise by the caller that every batch passed with this key and this shape carries the
+        SAME label matrix (the default loader: first column 1, negatives 0) — it is then uploaded once and kept on the
+        device instead of travelling with every batch."""
         dev = torch.device(self.net.device)
         u, i, lab = torch.as_tensor(u_idxs).long(), torch.as_tensor(i_idxs).long(), torch.as_tensor(labels).double()
         du, di = draws if draws is not None else self.draw(u.shape, i.shape)
@@ -367,6 +375,8 @@ class FusedTrainStep:
         pb.u_shape, pb.i_shape = tuple(u.shape), tuple(i.shape)
         pb.pu, pb.pi = self.user.plan(du, pad), self.item.plan(di, pad)
         pb.packed = pb.layout = None
+        pb.lab_cached = False
+        cached_lab = self._label_cache.get((labels_key, tuple(lab.shape))) if labels_key is not None else None
         if ahead and self._up_stream is None:
             self._up_stream = torch.cuda.Stream(dev)                 # the loader thread's upload stream
         stream = self._up_stream if ahead else torch.cuda.current_stream(dev)
@@ -375,7 +385,8 @@ class FusedTrainStep:
             if all(t.device.type == 'cpu' for t in parts):
                 # one packed H2D copy: [u | u[0] | i | i[0] | labels | user slots | item slots], 16-byte aligned segments
                 un, inn = parts[0].numpy(), parts[1].numpy()
-                arrs = [np.concatenate([un, un[:1]]), np.concatenate([inn, inn[:1]]), parts[2].numpy(),
+                arrs = [np.concatenate([un, un[:1]]), np.concatenate([inn, inn[:1]]),
+                        parts[2].numpy() if cached_lab is None else np.empty(0, np.float64),
                         pb.pu[0] if pb.pu is not None else np.empty(0, np.int32), pb.pi[0]]
                 offs = [0]
                 for a_ in arrs:
@@ -392,6 +403,11 @@ class FusedTrainStep:
                     ev.record(stream)                                # the staging slot is free again after this copy
                 pb.packed, pb.layout = packed, tuple((o, a_.nbytes) for a_, o in zip(arrs, offs))
                 pb.u, pb.i, pb.lab, pb.su, pb.si = self._views(packed, pb.layout, pb.pu is not None)
+                if cached_lab is not None:
+                    pb.lab, pb.lab_cached = cached_lab, True
+                elif labels_key is not None:
+                    keep = pb.lab.clone()                              # outlives this batch's packed buffer
+                    self._label_cache[(labels_key, tuple(lab.shape))] = keep
             else:                                                     # indices already on the device
                 def ext(t):
                     t = t.to(dev, non_blocking=True)
@@ -431,6 +447,8 @@ class FusedTrainStep:
         if pb.packed is not None:                                    # static copy of the packed upload: one D2D per replay
             cs.packed = torch.empty_like(pb.packed)
             cs.u, cs.i, cs.lab, cs.su, cs.si = self._views(cs.packed, pb.layout, pb.su is not None)
+            if pb.lab_cached:
+                cs.lab = pb.lab                                      # device-resident constant labels: nothing to copy
         else:
             cs.packed = None
             cs.u, cs.i, cs.lab = torch.empty_like(pb.u), torch.empty_like(pb.i), torch.empty_like(pb.lab)
@@ -467,7 +485,7 @@ class FusedTrainStep:
                 if self._arena_buf is not self.arena.buf:            # the arena moved: captured addresses are stale
                     self._graphs.clear()
                     self._arena_buf = self.arena.buf
-                key = (pb.u_shape, pb.i_shape, pb.pu[1:] if pb.pu is not None else None, pb.pi[1:])
+                key = (pb.u_shape, pb.i_shape, pb.pu[1:] if pb.pu is not None else None, pb.pi[1:], pb.lab_cached)
                 cs = self._graphs.get(key, 0)
                 if cs is None and self.arena.high <= self.arena.buf.numel():
                     cs = self._capture(key, pb)                      # second sighting: the arena is sized, capture
@@ -502,7 +520,7 @@ class FusedTrainStep:
 
 class PreparedBatch:
     """Device-resident inputs of one step + its launch plan (``FusedTrainStep.prepare``)."""
-    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'pu', 'pi', 'u_shape', 'i_shape', 'event')
+    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'pu', 'pi', 'u_shape', 'i_shape', 'event', 'lab_cached')
 
 
 _LIVE = weakref.WeakSet()

@@ -116,24 +116,42 @@ class DevicePositiveIndex:
 
 
 def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, items_in_split: np.ndarray,
-                             positives: PositiveIndex):
+                             positives: PositiveIndex, identity: Optional[bool] = None):
     """data/dataloader.py:154-198 with the same global-RNG calls: draw all B*n_neg slots, redraw only the colliding ones
-    (in ascending slot order) until none collides. Returns (users i64 [B], items i64 [B, 1+n_neg], labels f64)."""
+    (in ascending slot order) until none collides. Returns (users i64 [B], items i64 [B, 1+n_neg], labels f64).
+    ``identity``: whether items_in_split is 0..n-1 (computed when not given; loaders pass it once)."""
     user_idx = np.asarray(user_idx).astype(np.int64)
     b = len(user_idx)
     total = b * n_neg
-    values = np.zeros(total, dtype=np.int64)
+    n_cand = len(items_in_split)
+    if identity is None:
+        identity = is_arange(items_in_split)
+
+    def draw(m):
+        # np.random.choice(arr, m, replace=True) == arr[np.random.randint(0, len(arr), m)] on the legacy global stream
+        # (SURVEY.md §8(f).1, checked in tests/test_host_cpu.py); the lookup is skipped when arr is 0..n-1
+        r = np.random.randint(0, n_cand, size=m)
+        return r if identity else items_in_split[r]
+
     slot_user = np.tile(user_idx, n_neg)
-    todo = np.arange(total)
+    values = draw(total).astype(np.int64, copy=False)
+    todo = np.flatnonzero(positives.contains(slot_user, values))
     while len(todo) > 0:
-        values[todo] = np.random.choice(items_in_split, size=len(todo), replace=True)
+        values[todo] = draw(len(todo))
         todo = todo[positives.contains(slot_user[todo], values[todo])]
-    neg = values.reshape(n_neg, -1).T
-    items = np.column_stack([pos_item_idx, neg]).astype(np.int64)
-    labels = np.zeros_like(items, dtype=float)
-    n_pos = pos_item_idx.shape[-1] if np.ndim(pos_item_idx) > 1 else 1
+    items = np.empty((b, 1 + n_neg) if np.ndim(pos_item_idx) == 1 else (b, pos_item_idx.shape[-1] + n_neg), dtype=np.int64)
+    n_pos = items.shape[1] - n_neg
+    items[:, :n_pos] = np.asarray(pos_item_idx).reshape(b, n_pos)
+    items[:, n_pos:] = values.reshape(n_neg, b).T
+    labels = np.zeros(items.shape, dtype=float)
     labels[:, :n_pos] = 1.
     return user_idx, items, labels
+
+
+def is_arange(a: np.ndarray) -> bool:
+    """True when ``a`` is the identity map 0..n-1 (items_in_split of a split that keeps every item)."""
+    n = len(a)
+    return bool(n == 0 or (a[0] == 0 and a[-1] == n - 1 and np.array_equal(a, np.arange(n))))
 
 
 def uniform_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, n_items: int,

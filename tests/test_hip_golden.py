@@ -319,3 +319,37 @@ def test_fused_step_graph_replay_equals_plain_launches():
         # not bit-equal: split-K chunking follows the (padded) row counts and the table gradients use float atomics; AdamW at
         # lr 1e-2 turns that rounding noise into ~1e-6 absolute differences on near-zero gradients
         close(runs[1][2][k].double(), runs[0][2][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_loader_pipeline_equals_inline_steps():
+    """Batches prepared ahead by the loader's two producer threads (collate -> FusedTrainStep.prepare with pinned packed
+    uploads, device-cached labels, graph replay) train the model exactly like the same batches stepped inline."""
+    import sibrar_amd as S
+    cfg = {'shared_common_dim': 32, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [32], 'preference_hidden_layers': [], 'common_modality_dim': 32}}
+    finals = []
+    for piped in (False, True):
+        ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+        net.train()
+        opt = S.FusedOptimizer(net, 'adamw', lr=1e-2, weight_decay=1e-2)
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+        fused = S.FusedTrainStep(net, loss, opt, use_graph=piped)
+        loader = S.NegativeSamplingDataLoader(ds, batch_size=64, shuffle=True, device=DEV, max_batches=12,
+                                              prefetch=2 if piped else 0, prepare_fn=fused.prepare if piped else None)
+        losses = [torch.stack(fused.step(*b)).cpu() for b in loader]
+        loader.close()
+        assert len(losses) == 12
+        if piped:
+            assert fused.n_replays >= 4 and len(fused._label_cache) == 1
+        finals.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    for s_, (a, b) in enumerate(zip(finals[0][0], finals[1][0])):
+        close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
+    skip = set(bn_shadowed_biases(finals[0][1].keys())) | {'item_embedding_module.sb_net.1.bias'}
+    for k in finals[0][1]:
+        if k not in skip:
+            close(finals[1][1][k].double(), finals[0][1][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-4)

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int gn = n0 + (wn * NI + j) * 32 + l31;
-        if (gn >= g.N) continue;
+        if (gn >= g.N || acc[i][j][r] != 1234.5678f) continue;
         float v = acc[i][j][r];
         if (g.slab) {
           g.slab[((long)blockIdx.z * g.M + gm) * g.N + gn] = v;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     store_lds<BM, A_KM>(As, ra, t);
     store_lds<BN, B_KN>(Bs, rb, t);
     __syncthreads();
-    if (kbase + BK < kend) fetch(kbase + BK);   // in flight under the MFMAs below
+    /* no fetch */   // in flight under the MFMAs below
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       float4 fa[MI], fb[NI];

@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+          acc[i][j][0] += fa[i].x * fb[j].x;
+          acc[i][j][0] += fa[i].y * fb[j].y;
+          acc[i][j][0] += fa[i].z * fb[j].z;
+          acc[i][j][0] += fa[i].w * fb[j].w;
         }
     }
   }
