@@ -118,8 +118,23 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     return dt, timings
 
 
+def gemm_table(timings, steps):
+    """Every GEMM signature of the step, HIP-event timed: [{kernel, launches_per_step, avg_launch_ms, TFLOP/s, frac}] by time."""
+    rows = []
+    for key, ts in timings.items():
+        if key[0] != 'gemm_f32' or not ts:
+            continue
+        _, mode, M, N, K, gathered = key
+        avg_ms = sum(ts) / len(ts)
+        tf = 2.0 * M * N * K / (avg_ms * 1e-3) / 1e12
+        rows.append({'kernel': f'{["NT", "NN", "TN"][mode]} M={M} N={N} K={K}' + (' gathered' if gathered else ''),
+                     'launches_per_step': round(len(ts) / steps, 2), 'avg_launch_ms': round(avg_ms, 4),
+                     'ms_per_step': round(sum(ts) / steps, 4), 'tflops': round(tf, 2), 'frac': round(tf / PEAK_MFMA_F32, 4)})
+    return sorted(rows, key=lambda r: -r['ms_per_step'])
+
+
 def dominant_gemm(timings, steps):
-    """-> roofline dict of the GEMM signature with the largest total time over the timed region."""
+    """-> roofline dict of the GEMM signature with the largest total time over the timed steps."""
     best = None
     for key, ts in timings.items():
         if key[0] != 'gemm_f32' or not ts:
@@ -135,10 +150,12 @@ def dominant_gemm(timings, steps):
     achieved = flops / (avg_ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': None,
-            'kernel': f'gemm_f32_kernel mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}',
+            'kernel': f'fp32 MFMA GEMM (gemm_ring_kernel) mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
+                      + (' + split-K slab reduce' if mode == 2 else ''),
             'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps, 4),
             'timing': 'HIP events around every launch of this kernel over K plain-launch steps run right after the timed '
-                      'region (the timed region replays a hipGraph, which cannot carry per-kernel events)'}
+                      'region (the timed region replays a hipGraph, which cannot carry per-kernel events)',
+            'all_gemms': gemm_table(timings, steps)}
 
 
 def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
@@ -183,11 +200,37 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
                          'avg_launch_ms': round(avg_ms, 4)}}
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(os.cpu_count(), scheduler affinity, cgroup CPU quota). The GPU box
+    exposes every host thread through os.cpu_count() but grants a one-GPU job only a share of them; an OpenMP pool sized to
+    the whole machine then thrashes inside the quota (measured: 16 s per oracle step with 256 threads vs ~1.2 s)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(S, ds, net, batch, budget_s=20.0):
     """The CPU oracle restatement (oracle/) of the same training step on this box's host cores: same model parameters,
     same literal per-row sampling calls as the reference, torch-CPU fp32 ops, torch.optim.AdamW."""
     from oracle import model_ref, losses_ref, sampling_ref, train_ref
-    cores = os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     for v in sd.values():
@@ -205,20 +248,21 @@ def cpu_baseline(S, ds, net, batch, budget_s=20.0):
     positives = [inter.indices[inter.indptr[u]:inter.indptr[u + 1]] for u in range(ds.n_users)]
     coo = ds.interaction_matrix
     rng = np.random.default_rng(0)
-    n_steps, t_total = 0, 0.0
+    n_steps, t_total, step_s = 0, 0.0, []
     while t_total < budget_s and n_steps < 50:
         sel = rng.integers(0, coo.nnz, size=batch)
         t0 = time.perf_counter()
         u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
         train_ref.train_step(ref, loss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l))
         dt = time.perf_counter() - t0
+        step_s.append(round(dt, 3))
         if n_steps > 0 or dt > budget_s / 2:      # first step warms caches / allocators
             t_total += dt
         n_steps += 1
     timed = max(n_steps - 1, 1) if t_total > 0 else 1
     return {'value': round(batch * timed / max(t_total, 1e-9), 1), 'unit': 'interactions/s', 'cores': cores, 'kind': 'port',
             'sample': f'{timed} training steps of batch {batch} on the same c2 synthetic data (CPU oracle restatement, '
-                      f'torch {torch.__version__} CPU fp32, {cores} threads)'}
+                      f'torch {torch.__version__} CPU fp32, {cores} threads)', 'step_seconds': step_s}
 
 
 def main():
@@ -237,6 +281,7 @@ def main():
     # three Python threads hand batches to each other (collate -> prepare -> launch): with CPython's default 5 ms switch
     # interval a waiting thread can sit behind the GIL for longer than a whole B=256 step
     sys.setswitchinterval(float(os.environ.get('SBR_SWITCH_INTERVAL', '1e-3')))
+    torch.set_num_threads(host_cores())      # torch CPU ops of the loader threads: stay inside the job's CPU quota
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -370,7 +370,7 @@ class FusedTrainStep:
         dev = torch.device(self.net.device)
         u, i, lab = torch.as_tensor(u_idxs).long(), torch.as_tensor(i_idxs).long(), torch.as_tensor(labels).double()
         du, di = draws if draws is not None else self.draw(u.shape, i.shape)
-        pad = self.use_graph and not ops.KernelTimer.enabled
+        pad = self.use_graph          # also while KernelTimer forces plain launches: the timed launches keep the graph's shapes
         pb = PreparedBatch()
         pb.u_shape, pb.i_shape = tuple(u.shape), tuple(i.shape)
         pb.pu, pb.pi = self.user.plan(du, pad), self.item.plan(di, pad)
