@@ -144,6 +144,17 @@ int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, int N, int 
 int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
                     const float* grad_out, float* dA, float* dB, long ldg, void* stream);
 
+/* The same loss for groups of any size (in-batch contrast of B user rows, sgd_alg.py:1994-2002): the N x N logits go
+ * through the fp32 MFMA GEMMs (sbr_gemm_f32 / sbr_gemm_tn_f32) instead of LDS. workspace: sbr_infonce_gemm_workspace(N, D)
+ * bytes of device memory (logits, log-sum-exps, split-K slabs); groups are processed sequentially. Same argument meaning as
+ * sbr_infonce_fwd / sbr_infonce_bwd; the backward recomputes the logits. */
+long sbr_infonce_gemm_workspace(int N, int D);
+int sbr_infonce_gemm_fwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                         double* loss_out, void* workspace, long workspace_bytes, void* stream);
+int sbr_infonce_gemm_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                         const float* grad_out, float* dA, float* dB, long ldg, void* workspace, long workspace_bytes,
+                         void* stream);
+
 /* ---- dense optimizers over one flat fp32 buffer — train/trainer.py:62-68, 222 ---------------------------------------------
  * kind 0 = torch.optim.AdamW, 1 = torch.optim.Adam; step is the 1-based step count. */
 int sbr_adam_step(int kind, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,

@@ -200,3 +200,127 @@ extern "C" int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, 
   SBR_CHECK_LAUNCH("sbr_infonce_bwd");
   return SBR_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// InfoNCE for large groups (in-batch user contrast: ONE group of B rows, regularization_losses.py:14-43 called from
+// sgd_alg.py:1994-2002 with a [B, 2, D] tensor): the N x N logit matrix goes through the fp32 MFMA GEMMs instead of LDS.
+//   T = B_g A_g^T  -> column log-sum-exps (rows of the transpose)        S = A_g B_g^T -> row log-sum-exps, diagonal
+//   loss += scale * sum_i (lse_r[i] + lse_c[i] - 2 S_ii / tau)
+//   backward: S <- up * (softmax_rows + softmax_cols - 2 I), dA = S B_g (NN), dB = S^T A_g (TN, split-K slab reducer)
+// workspace: [N*N] logits | [N] lse_r | [N] lse_c | split-K slabs of the TN product. Groups are processed one after the other.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx,
+                            const float* bias, float* C, long ldc, const int* c_idx, int M, int N, int K, int act,
+                            int accumulate_atomic, void* stream);
+extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K);
+extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C,
+                               long ldc, int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
+
+// one wave per row: lse[i] = log sum_j exp(S[i][j] * inv_tau)
+__global__ void lse_rows_kernel(const float* __restrict__ S, int N, float inv_tau, float* __restrict__ lse) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const float* r = S + (long)row * N;
+  float mx = -INFINITY;
+  for (int j = lane; j < N; j += 64) mx = fmaxf(mx, r[j] * inv_tau);
+  mx = sbr_wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < N; j += 64) se += expf(r[j] * inv_tau - mx);
+  se = sbr_wave_sum(se);
+  if (lane == 0) lse[row] = mx + logf(se);
+}
+
+__global__ void infonce_gemm_loss_kernel(const float* __restrict__ S, int N, float inv_tau, const float* __restrict__ lse_r,
+                                         const float* __restrict__ lse_c, double scale, double* __restrict__ loss_out) {
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const double d = (double)(S[(long)i * N + i] * inv_tau);
+    acc += ((double)lse_r[i] - d) + ((double)lse_c[i] - d);
+  }
+  __shared__ double red[4];
+  const double t = block_sum_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
+}
+
+// S[i][j] <- up * (exp(l - lse_r[i]) + exp(l - lse_c[j]) - 2 [i == j]),  l = S[i][j] / tau,  up = gout * scale / tau
+__global__ void infonce_gemm_ds_kernel(float* __restrict__ S, int N, float inv_tau, const float* __restrict__ lse_r,
+                                       const float* __restrict__ lse_c, const float* __restrict__ gout, float scale) {
+  const float up = gout[0] * scale * inv_tau;
+  const long total = (long)N * N;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(p / N), j = (int)(p - (long)i * N);
+    const float l = S[p] * inv_tau;
+    S[p] = up * (expf(l - lse_r[i]) + expf(l - lse_c[j]) - (i == j ? 2.f : 0.f));
+  }
+}
+
+extern "C" long sbr_infonce_gemm_workspace(int N, int D) {
+  return ((long)N * N + 2L * N) * (long)sizeof(float) + sbr_gemm_tn_f32_workspace(N, D, N) + 256;
+}
+
+static int infonce_gemm_stats(const float* a, const float* b, long ld, int N, int D, float inv_tau, float* S, float* lse_r,
+                              float* lse_c, hipStream_t s) {
+  // column statistics from the transposed product, then the product itself (left in S)
+  int rc = sbr_gemm_f32(0, b, ld, nullptr, a, ld, nullptr, nullptr, S, N, nullptr, N, N, D, SBR_ACT_NONE, 0, s);
+  if (rc) return rc;
+  lse_rows_kernel<<<sbr_cdiv(N, 4), 256, 0, s>>>(S, N, inv_tau, lse_c);
+  SBR_CHECK_LAUNCH("sbr_infonce_gemm/lse_c");
+  rc = sbr_gemm_f32(0, a, ld, nullptr, b, ld, nullptr, nullptr, S, N, nullptr, N, N, D, SBR_ACT_NONE, 0, s);
+  if (rc) return rc;
+  lse_rows_kernel<<<sbr_cdiv(N, 4), 256, 0, s>>>(S, N, inv_tau, lse_r);
+  SBR_CHECK_LAUNCH("sbr_infonce_gemm/lse_r");
+  return SBR_OK;
+}
+
+extern "C" int sbr_infonce_gemm_fwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                                    double* loss_out, void* workspace, long workspace_bytes, void* stream) {
+  SBR_REQUIRE(A && B && loss_out, "sbr_infonce_gemm_fwd: null operand");
+  SBR_REQUIRE(N >= 1 && D >= 1, "sbr_infonce_gemm_fwd: bad shape");
+  SBR_REQUIRE(workspace && workspace_bytes >= sbr_infonce_gemm_workspace(N, D), "sbr_infonce_gemm_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_infonce_gemm_fwd: memset failed"); return SBR_ERR_HIP; }
+  float* S = (float*)workspace;
+  float* lse_r = S + (long)N * N;
+  float* lse_c = lse_r + N;
+  for (long g = 0; g < G; ++g) {
+    const float* a = A + g * N * ld;
+    const float* b = B + g * N * ld;
+    int rc = infonce_gemm_stats(a, b, ld, N, D, 1.f / tau, S, lse_r, lse_c, s);
+    if (rc) return rc;
+    infonce_gemm_loss_kernel<<<sbr_cdiv(N, 256) > 64 ? 64 : sbr_cdiv(N, 256), 256, 0, s>>>(S, N, 1.f / tau, lse_r, lse_c, scale, loss_out);
+    SBR_CHECK_LAUNCH("sbr_infonce_gemm_fwd");
+  }
+  return SBR_OK;
+}
+
+extern "C" int sbr_infonce_gemm_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
+                                    const float* grad_out, float* dA, float* dB, long ldg, void* workspace,
+                                    long workspace_bytes, void* stream) {
+  SBR_REQUIRE(A && B && grad_out && dA && dB, "sbr_infonce_gemm_bwd: null operand");
+  SBR_REQUIRE(N >= 1 && D >= 1, "sbr_infonce_gemm_bwd: bad shape");
+  SBR_REQUIRE(workspace && workspace_bytes >= sbr_infonce_gemm_workspace(N, D), "sbr_infonce_gemm_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* S = (float*)workspace;
+  float* lse_r = S + (long)N * N;
+  float* lse_c = lse_r + N;
+  char* tn_ws = (char*)(((uintptr_t)(lse_c + N) + 255) & ~(uintptr_t)255);
+  const long tn_bytes = sbr_gemm_tn_f32_workspace(N, D, N);
+  for (long g = 0; g < G; ++g) {
+    const float* a = A + g * N * ld;
+    const float* b = B + g * N * ld;
+    int rc = infonce_gemm_stats(a, b, ld, N, D, 1.f / tau, S, lse_r, lse_c, s);
+    if (rc) return rc;
+    const long total = (long)N * N;
+    const int blocks = (int)(sbr_cdiv(total, 256) > 4096 ? 4096 : sbr_cdiv(total, 256));
+    infonce_gemm_ds_kernel<<<blocks, 256, 0, s>>>(S, N, 1.f / tau, lse_r, lse_c, grad_out, (float)scale);
+    SBR_CHECK_LAUNCH("sbr_infonce_gemm_bwd/ds");
+    // dA[i] = sum_j G[i][j] B[j]   (NN: [N x N] @ [N x D]);   dB[i] = sum_j G[j][i] A[j]   (TN over the N rows)
+    rc = sbr_gemm_f32(1, S, N, nullptr, b, ld, nullptr, nullptr, dA + g * N * ldg, ldg, nullptr, N, D, N, SBR_ACT_NONE, 0, s);
+    if (rc) return rc;
+    rc = sbr_gemm_tn_f32(S, N, nullptr, a, ld, nullptr, dB + g * N * ldg, ldg, N, D, N, tn_ws, tn_bytes, s);
+    if (rc) return rc;
+  }
+  return SBR_OK;
+}

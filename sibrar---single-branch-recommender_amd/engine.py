@@ -172,13 +172,11 @@ class _EntityRun:
                 raise SystemError('second last dimension of embeddings should be of size 2')
             N = self.shape[-1]
             G = S // N
-            if N > ops.infonce_max_n():
-                raise NotImplementedError(f'InfoNCE over {N} rows per group exceeds the on-chip kernel limit')
             self.G, self.N = G, N
             self.reg_loss = a.f64()
             e3 = x.view(S, 2, self.D)
-            call('sbr_infonce_fwd', e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * self.D, G, N, self.D, self.tau,
-                 1.0 / (G * N), ptr(self.reg_loss), st)
+            ops.infonce_fwd(e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * self.D, G, N, self.D, self.tau, 1.0 / (G * N),
+                            self.reg_loss, x.device)
         if k == 1:
             return x.view(S, self.D)
         out = a.f32(S, self.D)
@@ -216,8 +214,8 @@ class _EntityRun:
             dreg = a.f32(R, D)
             e3, d3 = self.e.view(S, 2, D), dreg.view(S, 2, D)
             # d(total)/d(reg_loss) = regularization_weight (sgd_alg.py:2002); mean over G*N rows inside the kernel
-            call('sbr_infonce_bwd', e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * D, self.G, self.N, D, self.tau,
-                 self.reg_w / (self.G * self.N), ptr(one_f32), d3[:, 0].data_ptr(), d3[:, 1].data_ptr(), 2 * D, st)
+            ops.infonce_bwd(e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * D, self.G, self.N, D, self.tau,
+                            self.reg_w / (self.G * self.N), one_f32, d3[:, 0].data_ptr(), d3[:, 1].data_ptr(), 2 * D, dreg.device)
             de = de.add_(dreg) if k > 1 else dreg.add_(de)
         d = de
         if self.tb is not None:

@@ -361,6 +361,41 @@ class RecLossFn(Function):
         return d, None, None, None, None
 
 
+_INFONCE_WS = {}
+
+
+def infonce_uses_gemm(G: int, N: int) -> bool:
+    """Large groups (in-batch contrast) go through the MFMA GEMMs; many small groups stay in the one-workgroup-per-group
+    kernel whose logits live in LDS."""
+    return N > infonce_max_n() or (N > 32 and G < 32)
+
+
+def _infonce_ws(device, N, D):
+    from ._lib import lib
+    need = lib().sbr_infonce_gemm_workspace(N, D)
+    ws = _INFONCE_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _INFONCE_WS[device] = torch.empty(need, device=device, dtype=torch.uint8)
+    return ws
+
+
+def infonce_fwd(a_ptr, b_ptr, ld, G, N, D, tau, scale, loss_out, device):
+    if infonce_uses_gemm(G, N):
+        ws = _infonce_ws(device, N, D)
+        call('sbr_infonce_gemm_fwd', a_ptr, b_ptr, ld, G, N, D, tau, scale, ptr(loss_out), ptr(ws), ws.numel(), stream())
+    else:
+        call('sbr_infonce_fwd', a_ptr, b_ptr, ld, G, N, D, tau, scale, ptr(loss_out), stream())
+
+
+def infonce_bwd(a_ptr, b_ptr, ld, G, N, D, tau, scale, gout, da_ptr, db_ptr, ldg, device):
+    if infonce_uses_gemm(G, N):
+        ws = _infonce_ws(device, N, D)
+        call('sbr_infonce_gemm_bwd', a_ptr, b_ptr, ld, G, N, D, tau, scale, ptr(gout), da_ptr, db_ptr, ldg, ptr(ws), ws.numel(),
+             stream())
+    else:
+        call('sbr_infonce_bwd', a_ptr, b_ptr, ld, G, N, D, tau, scale, ptr(gout), da_ptr, db_ptr, ldg, stream())
+
+
 class InfoNCEFn(Function):
     """train/regularization_losses.py:14-43 on two [G, N, D] views that may be strided slices of one [G*N, 2, D] tensor."""
 
@@ -372,8 +407,7 @@ class InfoNCEFn(Function):
         D = e.shape[-1]
         out = torch.empty((), device=e.device, dtype=torch.float64)
         scale = 1.0 / (G * N) if mean else 1.0
-        a, b = e[:, 0], e[:, 1]
-        call('sbr_infonce_fwd', a.data_ptr(), b.data_ptr(), 2 * D, G, N, D, tau, scale, ptr(out), stream())
+        infonce_fwd(e[:, 0].data_ptr(), e[:, 1].data_ptr(), 2 * D, G, N, D, tau, scale, out, e.device)
         ctx.args = (tau, scale, G, N, D)
         ctx.save_for_backward(e)
         return out.float()
@@ -384,8 +418,8 @@ class InfoNCEFn(Function):
         tau, scale, G, N, D = ctx.args
         g = g.float().contiguous()
         de = torch.empty_like(e)
-        call('sbr_infonce_bwd', e[:, 0].data_ptr(), e[:, 1].data_ptr(), 2 * D, G, N, D, tau, scale, ptr(g),
-             de[:, 0].data_ptr(), de[:, 1].data_ptr(), 2 * D, stream())
+        infonce_bwd(e[:, 0].data_ptr(), e[:, 1].data_ptr(), 2 * D, G, N, D, tau, scale, g, de[:, 0].data_ptr(),
+                    de[:, 1].data_ptr(), 2 * D, e.device)
         return de, None, None, None, None
 
 

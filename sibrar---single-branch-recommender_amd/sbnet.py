@@ -515,9 +515,6 @@ class SingleBranchNetEntity(nn.Module):
         # InfoNCE over the last index dimension: [B, N] -> B groups of N; [B] -> one group of B (in-batch)
         N = int(index_shape[-1])
         G = int(np.prod(index_shape[:-1])) if len(index_shape) > 1 else 1
-        if N > ops.infonce_max_n():
-            raise NotImplementedError(f'InfoNCE over {N} rows per group exceeds the on-chip kernel limit '
-                                      f'({ops.infonce_max_n()})')
         self.regularization_loss = ops.InfoNCEFn.apply(e, float(self.entity_config.regularization_temperature), True, G, N)
 
     def _zero_loss(self):

@@ -241,10 +241,12 @@ def test_g11_sgd_baseline():
     close(m(u, i).detach().cpu(), z['logits'], what='logits(train)', **TOL)
 
 
-@pytest.mark.parametrize('user_kind,loss_name', [('lookup', 'bpr'), ('entity', 'ssm_uniform'), ('linear', 'bce')])
-def test_fused_step_matches_autograd_path(user_kind, loss_name):
+@pytest.mark.parametrize('user_kind,loss_name,B', [('lookup', 'bpr', 6), ('entity', 'ssm_uniform', 6), ('linear', 'bce', 6),
+                                                   ('entity', 'bpr', 300)])
+def test_fused_step_matches_autograd_path(user_kind, loss_name, B):
     """engine.FusedTrainStep (hand-written backward, no autograd) == module path (autograd over the same kernels): same
-    losses and the same parameters after three AdamW steps on the golden world."""
+    losses and the same parameters after three AdamW steps on the golden world. B = 300 with an entity user side is the
+    in-batch InfoNCE over 300 user rows (GEMM path of the loss; the on-chip kernel holds at most 176 rows)."""
     import sibrar_amd as S
     z = load('g4_full_net')
     case = [c for c in MANIFEST['g4_full_net']['cases'] if c['name'] == f'{user_kind}_bpr'][0]
@@ -255,9 +257,9 @@ def test_fused_step_matches_autograd_path(user_kind, loss_name):
     fused = S.FusedTrainStep(nets[1], _loss(loss_name), opts[1])
     rng = np.random.default_rng(5)
     for s_ in range(3):
-        u = torch.from_numpy(rng.integers(0, U, size=6))
-        i = torch.from_numpy(rng.integers(0, I, size=(6, 4)))
-        labels = torch.zeros(6, 4, dtype=torch.float64)
+        u = torch.from_numpy(rng.integers(0, U, size=B))
+        i = torch.from_numpy(rng.integers(0, I, size=(B, 4)))
+        labels = torch.zeros(B, 4, dtype=torch.float64)
         labels[:, 0] = 1
         logits = nets[0](u.to(DEV), i.to(DEV))
         loss = _loss(loss_name).compute_loss(logits, labels.to(DEV))

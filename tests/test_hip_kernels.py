@@ -167,7 +167,8 @@ def test_rec_losses_vs_oracle(kind, agg, B, N):
         close(ld.grad.cpu(), lr.grad, rtol=1e-4, atol=1e-7, what='dlogits', norm_rtol=1e-5)
 
 
-@pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8)])
+@pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8), (64, 40, 16), (1, 256, 64), (2, 300, 30),
+                                   (1, 1000, 128)])
 def test_infonce_vs_oracle(G, N, D):
     import sibrar_amd as Sm
     from oracle import model_ref
