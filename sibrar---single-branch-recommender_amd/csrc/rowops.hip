@@ -197,13 +197,97 @@ __global__ void csr_project_bwd_kernel(const long* __restrict__ indptr, const in
   }
 }
 
+// Workgroup-per-row variants (C % 4 == 0, 16-byte aligned weight rows). Interaction rows are long-tailed (a popular item
+// has thousands of nnz, the median a few dozen): one wave walking one row serialises the tail, so a row is spread over the
+// whole workgroup. Forward: 256 threads = G nnz-groups x (C/4) lanes, each lane accumulates a float4 of the output row over
+// every G-th nnz (four nnz in flight per lane), groups are combined through LDS. Backward: the four waves take 64-nnz blocks
+// round robin; a block's column indices are loaded once (one per lane) and broadcast, and every nnz becomes one
+// 256-byte-contiguous float atomic per 64 columns (the full-rate form, MI355X_MICROARCH.md "float atomic add").
+__global__ __launch_bounds__(256) void csr_project_fwd_wg_kernel(
+    const long* __restrict__ indptr, const int* __restrict__ indices, const float* __restrict__ vals,
+    const float* __restrict__ Wt, long ldw, const float* __restrict__ bias, const int* __restrict__ rows,
+    float* __restrict__ out, long ldo, const int* __restrict__ out_idx, int C, int act) {
+  __shared__ float4 part[256];
+  const long j = blockIdx.x;
+  const int t = threadIdx.x;
+  const int LPG = C >> 2;                 // lanes per nnz group
+  const int G = 256 / LPG;                // nnz groups (>= 1: C <= 1024)
+  const int g = t / LPG, l = t - g * LPG;
+  const long r = rows[j];
+  const long beg = indptr[r], end = indptr[r + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+    long q = beg + g;
+    for (; q + 3L * G < end; q += 4L * G) {
+      const int i0 = indices[q], i1 = indices[q + G], i2 = indices[q + 2L * G], i3 = indices[q + 3L * G];
+      const float4 w0 = *reinterpret_cast<const float4*>(Wt + (long)i0 * ldw + 4 * l);
+      const float4 w1 = *reinterpret_cast<const float4*>(Wt + (long)i1 * ldw + 4 * l);
+      const float4 w2 = *reinterpret_cast<const float4*>(Wt + (long)i2 * ldw + 4 * l);
+      const float4 w3 = *reinterpret_cast<const float4*>(Wt + (long)i3 * ldw + 4 * l);
+      const float v0 = vals ? vals[q] : 1.f, v1 = vals ? vals[q + G] : 1.f, v2 = vals ? vals[q + 2L * G] : 1.f,
+                  v3 = vals ? vals[q + 3L * G] : 1.f;
+      acc.x += v0 * w0.x + v1 * w1.x + v2 * w2.x + v3 * w3.x;
+      acc.y += v0 * w0.y + v1 * w1.y + v2 * w2.y + v3 * w3.y;
+      acc.z += v0 * w0.z + v1 * w1.z + v2 * w2.z + v3 * w3.z;
+      acc.w += v0 * w0.w + v1 * w1.w + v2 * w2.w + v3 * w3.w;
+    }
+    for (; q < end; q += G) {
+      const float4 w = *reinterpret_cast<const float4*>(Wt + (long)indices[q] * ldw + 4 * l);
+      const float v = vals ? vals[q] : 1.f;
+      acc.x += v * w.x; acc.y += v * w.y; acc.z += v * w.z; acc.w += v * w.w;
+    }
+  }
+  part[t] = acc;
+  __syncthreads();
+  if (t < LPG) {
+    float4 s = part[t];
+    for (int k = 1; k < G; ++k) {
+      const float4 p = part[k * LPG + t];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    if (bias) { s.x += bias[4 * t]; s.y += bias[4 * t + 1]; s.z += bias[4 * t + 2]; s.w += bias[4 * t + 3]; }
+    float* o = out + (out_idx ? (long)out_idx[j] : j) * ldo + 4 * t;
+    o[0] = sbr_act(s.x, act); o[1] = sbr_act(s.y, act); o[2] = sbr_act(s.z, act); o[3] = sbr_act(s.w, act);
+  }
+}
+
+template <int NC>   // NC = ceil(C / 64) column chunks per lane
+__global__ __launch_bounds__(256) void csr_project_bwd_wg_kernel(
+    const long* __restrict__ indptr, const int* __restrict__ indices, const float* __restrict__ vals,
+    const float* __restrict__ dZ, long ldz, const int* __restrict__ rows, float* __restrict__ dWt, long ldw, int C) {
+  const long j = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = rows[j];
+  const long beg = indptr[r], end = indptr[r + 1];
+  float g[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) g[i] = (lane + 64 * i < C) ? dZ[j * ldz + lane + 64 * i] : 0.f;
+  for (long base = beg + 64L * wave; base < end; base += 256) {
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    const int my_idx = lane < cnt ? indices[base + lane] : 0;
+    const float my_val = (vals && lane < cnt) ? vals[base + lane] : 1.f;
+    for (int k = 0; k < cnt; ++k) {
+      const long row = (long)__shfl(my_idx, k, 64) * ldw;
+      const float v = __shfl(my_val, k, 64);
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        if (lane + 64 * i < C) atomicAdd(&dWt[row + lane + 64 * i], v * g[i]);
+    }
+  }
+}
+
 extern "C" int sbr_csr_project_fwd(const long* indptr, const int* indices, const float* vals, const float* Wt, long ldw,
                                    const float* bias, const int* rows, float* out, long ldo, const int* out_idx, long n,
                                    int C, int act, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(indptr && indices && Wt && rows && out, "sbr_csr_project_fwd: null operand");
-  csr_project_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out,
-                                                                          ldo, out_idx, n, C, act);
+  if ((C & 3) == 0 && C <= 1024 && (ldw & 3) == 0 && (((uintptr_t)Wt) & 15) == 0) {
+    csr_project_fwd_wg_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out, ldo,
+                                                                           out_idx, C, act);
+  } else {
+    csr_project_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out,
+                                                                            ldo, out_idx, n, C, act);
+  }
   SBR_CHECK_LAUNCH("sbr_csr_project_fwd");
   return SBR_OK;
 }
@@ -212,7 +296,17 @@ extern "C" int sbr_csr_project_bwd(const long* indptr, const int* indices, const
                                    const int* rows, float* dWt, long ldw, long n, int C, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(indptr && indices && dZ && rows && dWt, "sbr_csr_project_bwd: null operand");
-  csr_project_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, n, C);
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = sbr_cdiv(C, 64);
+  switch (nc) {
+    case 1: csr_project_bwd_wg_kernel<1><<<(unsigned)n, 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, C); break;
+    case 2: csr_project_bwd_wg_kernel<2><<<(unsigned)n, 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, C); break;
+    case 3: case 4: csr_project_bwd_wg_kernel<4><<<(unsigned)n, 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, C); break;
+    case 5: case 6: case 7: case 8:
+      csr_project_bwd_wg_kernel<8><<<(unsigned)n, 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, C); break;
+    default:
+      csr_project_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, n, C);
+  }
   SBR_CHECK_LAUNCH("sbr_csr_project_bwd");
   return SBR_OK;
 }

@@ -142,17 +142,23 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
                 pass
         users = np.asarray(dataset.users_in_split)
         bs = int(getattr(eval_loader, 'batch_size', 256) or 256)
+        if scorer not in ('fp32', 'fp16_fused'):
+            raise ValueError(f'unknown scorer {scorer!r}')
+        if scorer == 'fp16_fused' and (kmax > 32 or i_repr.shape[1] not in (64, 128, 256)):
+            # the fused kernel keeps at most 32 candidates per user on chip and is built for D in {64, 128, 256}: larger
+            # cut-offs (the reference's default evaluator asks for top-100) take the exact fp32 GEMM + radix-select path
+            import logging
+            logging.info(f'fp16_fused scorer: k={kmax}, D={i_repr.shape[1]} outside the fused kernel, using the fp32 path')
+            scorer = 'fp32'
         i16 = ops.cast_f16(i_repr) if scorer == 'fp16_fused' else None
         for s in range(0, len(users), bs):
             u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
             u_repr = alg.get_user_representations(u_idxs)
             if scorer == 'fp16_fused':
                 _, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1])
-            elif scorer == 'fp32':
+            else:
                 out = alg.combine_user_item_representations(u_repr, i_repr)
                 ops.mask_scores_(out, u_idxs, excl[0], excl[1])
                 _, idx = ops.topk_rows(out, kmax)
-            else:
-                raise ValueError(f'unknown scorer {scorer!r}')
             evaluator.eval_topk(u_idxs, idx)
     return evaluator.get_results(return_raw_results=return_raw)

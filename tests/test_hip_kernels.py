@@ -319,3 +319,49 @@ def test_full_size_properties_c2_shapes():
     tv, ti = ops.topk_rows(sc, 20)
     close(val.cpu(), tv.cpu(), rtol=1e-4, atol=1e-5, what='fused vs unfused values')
     assert (idx == ti).float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize('C,act', [(64, 1), (128, 0), (48, 2), (512, 1), (30, 0)])
+def test_csr_projector_long_tailed_rows(C, act):
+    """CSR 'interactions' projector (Feature.py:149-150 toarray() + Linear, sgd_alg.py:1380) on long-tailed rows: one row
+    with thousands of nnz, empty rows, repeated rows in the batch; forward and dW against dense torch fp32.
+    C = 30 takes the generic wave-per-row kernel, the others the workgroup-per-row kernels."""
+    import scipy.sparse as sp
+    import importlib
+    mod = S()
+    _lib = importlib.import_module(mod.ops.__name__.rsplit('.', 1)[0] + '._lib')
+    call, ptr, ops = _lib.call, _lib.ptr, mod.ops
+    n_rows, n_cols = 50, 6000
+    rng = np.random.default_rng(C)
+    lens = np.array([0, 1, 3, 5000, 700, 64, 65, 255, 256, 257] + list(rng.integers(0, 120, size=n_rows - 10)))
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, size=l, replace=False)) for l in lens]).astype(np.int32)
+    vals = rng.standard_normal(indices.size).astype(np.float32)
+    dense = torch.from_numpy(sp.csr_matrix((vals, indices, indptr), shape=(n_rows, n_cols)).toarray())
+    W = _rand(C, n_cols, seed=90) * 0.05
+    b = _rand(C, seed=91)
+    rows = torch.from_numpy(np.concatenate([np.arange(n_rows), [3, 3, 0, 4]]).astype(np.int32))
+    n = rows.numel()
+    slots = torch.from_numpy(rng.permutation(n).astype(np.int32))
+    wt = W.t().contiguous().to(DEV)                      # column-major projector weight: [n_cols, C]
+    # every device operand stays referenced until the results are read back (a temporary's memory is recycled at once)
+    b_d, rows_d, slots_d = b.to(DEV), rows.to(DEV), slots.to(DEV)
+    for use_vals in (True, False):
+        d = dense if use_vals else (dense != 0).float()
+        ref_pre = d[rows.long()] @ W.t() + b
+        ref = {0: ref_pre, 1: torch.relu(ref_pre), 2: torch.tanh(ref_pre)}[act]
+        out = torch.zeros(n, C, device=DEV)
+        dv = torch.from_numpy(vals).to(DEV) if use_vals else None
+        ip, ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+        call('sbr_csr_project_fwd', ptr(ip), ptr(ix), ptr(dv), ptr(wt), wt.stride(0), ptr(b_d), ptr(rows_d),
+             ptr(out), out.stride(0), ptr(slots_d), n, C, act, ops.stream())
+        got = torch.empty_like(ref)
+        got[:] = out.cpu()[slots.long()]
+        close(got, ref, rtol=1e-4, atol=1e-5, what=f'csr fwd vals={use_vals}', norm_rtol=1e-5)
+        dz = _rand(n, C, seed=92)
+        dz_d = dz.to(DEV)
+        dwt = torch.zeros_like(wt)
+        call('sbr_csr_project_bwd', ptr(ip), ptr(ix), ptr(dv), ptr(dz_d), C, ptr(rows_d), ptr(dwt), dwt.stride(0),
+             n, C, ops.stream())
+        ref_dw = dz.t() @ d[rows.long()]                  # [C, n_cols]
+        close(dwt.cpu().t(), ref_dw, rtol=1e-4, atol=1e-5, what=f'csr dW vals={use_vals}', norm_rtol=1e-5)
