@@ -79,6 +79,11 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
                                    neg_train=ds.n_negative_samples)
     trainer = S.Trainer(net, None, None, loss, _Conf(device))
     net.train()
+    # three Python threads hand batches to each other (collate -> prepare -> launch). With CPython's default 5 ms switch
+    # interval a waiting thread can sit behind the GIL for longer than a whole small-batch step; measured best: 0.2 ms at
+    # B = 256 (0.36 vs 0.59 ms per step), 1 ms at B = 8192.
+    if 'SBR_SWITCH_INTERVAL' not in os.environ:
+        sys.setswitchinterval(2e-4 if batch <= 1024 else 1e-3)
     # weak scaling: every rank collates its own per-GPU batch (dp_sampling='local': contiguous slice of the shared epoch order,
     # rank-seeded negative stream) — the bit-exact 'global' mode makes every rank draw the whole global batch on its host
     np.random.seed(42 + rank)
@@ -104,8 +109,13 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
         # per-kernel HIP events cannot be recorded inside a hipGraph replay: the next `steps` batches of the same loader are
         # run with plain launches (KernelTimer on switches the graph off) and every GEMM launch is bracketed by events on
         # the launch stream. Outside the timed region; same kernels, same shapes, same data stream.
+        # Each of these steps starts behind a ~2 ms spin kernel so that the host has queued the whole step before its first
+        # kernel starts: otherwise the GPU idles between plain launches and every bracketed kernel starts "cold" (measured:
+        # 55 us instead of the 38 us rocprofv3 reports for the same dispatch inside the graph replay).
         S.ops.KernelTimer.reset(True)
-        run_steps(S, trainer, it, steps, world)
+        for _ in range(steps):
+            torch.cuda._sleep(5_000_000)
+            trainer.train_step(*next(it))
         timings = S.ops.KernelTimer.results()
         S.ops.KernelTimer.reset(False)
     loader.close()
@@ -154,7 +164,8 @@ def dominant_gemm(timings, steps):
                       + (' + split-K slab reduce' if mode == 2 else ''),
             'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps, 4),
             'timing': 'HIP events around every launch of this kernel over K plain-launch steps run right after the timed '
-                      'region (the timed region replays a hipGraph, which cannot carry per-kernel events)',
+                      'region (the timed region replays a hipGraph, which cannot carry per-kernel events); each of those steps '
+                      'is queued behind a spin kernel so that its kernels run back to back as they do in the replay',
             'all_gemms': gemm_table(timings, steps)}
 
 
@@ -278,9 +289,8 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
-    # three Python threads hand batches to each other (collate -> prepare -> launch): with CPython's default 5 ms switch
-    # interval a waiting thread can sit behind the GIL for longer than a whole B=256 step
-    sys.setswitchinterval(float(os.environ.get('SBR_SWITCH_INTERVAL', '1e-3')))
+    if 'SBR_SWITCH_INTERVAL' in os.environ:
+        sys.setswitchinterval(float(os.environ['SBR_SWITCH_INTERVAL']))
     torch.set_num_threads(host_cores())      # torch CPU ops of the loader threads: stay inside the job's CPU quota
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -54,6 +54,12 @@ long sbr_gemm_tn_f32_workspace(int M, int N, int K);
 int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C, long ldc,
                     int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
 
+/* Stable counting sort of the modality draw: the boolean-mask grouping of the flattened index tensor by sampled modality
+ * (algorithms/sgd_alg.py:1934-1957). pos: int8 [R] modality position of every slot; segment m of slots_out
+ * ([seg_offsets[m], seg_offsets[m+1]), HOST array of n_mod + 1 offsets, n_mod <= 8) receives the slots of modality m in
+ * ascending order, its unused tail (capacity > count) is filled with the sentinel R. */
+int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* seg_offsets, int* slots_out, void* stream);
+
 /* ---- index plumbing ----------------------------------------------------------------------------------------------------
  * rows_out[j] = rowmap_seg(j)[ idx[slots[j] / k] ] for the concatenated per-modality slot lists (segment s covers
  * [seg_offsets[s], seg_offsets[s+1])): the id -> row lookup of Feature.__getitem__ (data/Feature.py:146) on the

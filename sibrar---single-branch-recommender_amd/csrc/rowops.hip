@@ -43,6 +43,78 @@ extern "C" int sbr_resolve_rows(const long* idx, int k, const int* slots, int n,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stable counting sort of the modality draw (sgd_alg.py:1934-1957 groups the flattened index tensor by sampled modality
+// with boolean masks): slots_out[seg_off[m] + r] = index of the r-th slot (ascending) whose modality is m; the tail of every
+// segment (capacity - count, the padding of a graph-mode plan) is filled with the sentinel slot R.
+// One workgroup of 1024 threads: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk) — contiguous chunks + an
+// exclusive scan over the per-thread counts keep the order stable. R is ~1e5: the kernel is latency-sized (~20 us).
+// ---------------------------------------------------------------------------------------------------------------
+#define SBR_PART_MAX 8
+struct PartSeg { int n_mod; int offs[SBR_PART_MAX + 1]; };
+
+__global__ __launch_bounds__(1024) void partition_slots_kernel(const signed char* __restrict__ pos, long R, PartSeg sg,
+                                                               int* __restrict__ slots_out) {
+  __shared__ int cnt[SBR_PART_MAX][1024];
+  const int t = threadIdx.x;
+  const long total = sg.offs[sg.n_mod];
+  for (long e = t; e < total; e += 1024) slots_out[e] = (int)R;
+  const long chunk = (R + 1023) / 1024;
+  const long lo = t * chunk, hi = (lo + chunk < R) ? lo + chunk : R;
+  int local[SBR_PART_MAX];
+#pragma unroll
+  for (int m = 0; m < SBR_PART_MAX; ++m) local[m] = 0;
+  for (long e = lo; e < hi; ++e) {
+    const int m = pos[e];
+#pragma unroll
+    for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (m == q);
+  }
+#pragma unroll
+  for (int m = 0; m < SBR_PART_MAX; ++m) cnt[m][t] = local[m];
+  __syncthreads();
+  // exclusive scan of each modality's 1024 counts: wave w scans modality w, w + 16, ... (16 values per lane + wave scan)
+  const int lane = t & 63, wave = t >> 6;
+  for (int m = wave; m < sg.n_mod; m += 16) {   // 16 waves, at most 8 modalities: one wave each
+    int v[16], s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = cnt[m][lane * 16 + i]; s += v[i]; }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    int run = incl - s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cnt[m][lane * 16 + i] = run; run += v[i]; }
+  }
+  __syncthreads();
+  int w[SBR_PART_MAX];
+#pragma unroll
+  for (int m = 0; m < SBR_PART_MAX; ++m) w[m] = (m < sg.n_mod) ? sg.offs[m] + cnt[m][t] : 0;
+  __syncthreads();               // the fill above and the writes below touch the same array: order them
+  for (long e = lo; e < hi; ++e) {
+    const int m = pos[e];
+#pragma unroll
+    for (int q = 0; q < SBR_PART_MAX; ++q)
+      if (m == q) slots_out[w[q]++] = (int)e;
+  }
+}
+
+extern "C" int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* seg_offsets, int* slots_out,
+                                   void* stream) {
+  SBR_REQUIRE(n_mod >= 1 && n_mod <= SBR_PART_MAX, "sbr_partition_slots: n_mod %d out of range", n_mod);
+  SBR_REQUIRE(R >= 0 && R < 2147483647L, "sbr_partition_slots: R out of range");
+  SBR_REQUIRE(pos && seg_offsets && slots_out, "sbr_partition_slots: null operand");
+  PartSeg sg;
+  sg.n_mod = n_mod;
+  for (int i = 0; i <= n_mod; ++i) sg.offs[i] = seg_offsets[i];
+  if (sg.offs[n_mod] == 0) return SBR_OK;
+  partition_slots_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pos, R, sg, slots_out);
+  SBR_CHECK_LAUNCH("sbr_partition_slots");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // nn.Embedding lookup (sgd_alg.py:1331,1386): out[oi(j), :] = W[rows[j], :]
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void gather_rows_kernel(const float* __restrict__ W, long ldw, const int* __restrict__ rows,

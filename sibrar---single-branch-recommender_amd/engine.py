@@ -56,6 +56,10 @@ class Arena:
         n = int(np.prod(shape)) if shape else 1
         return self._take(4 * n, torch.float32, shape)
 
+    def i32(self, *shape):
+        n = int(np.prod(shape)) if shape else 1
+        return self._take(4 * n, torch.int32, shape)
+
     def f64(self, *shape):
         n = int(np.prod(shape)) if shape else 1
         return self._take(8 * n, torch.float64, shape)
@@ -87,7 +91,9 @@ class _EntityRun:
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def plan(self, draw: Tuple[np.ndarray, list], pad: bool = False):
-        """Host part of a step: counting sort of the modality draw -> (slot order int32, k, rows per modality, order, R).
+        """Host part of a step: -> (modality position of every slot int8 [R], k, rows per modality, order, R, padded).
+        The stable counting sort itself (slot lists per modality) runs on the GPU (``sbr_partition_slots``); the host only
+        counts, because the per-modality row counts are the launch sizes.
 
         ``pad`` (graph mode): the number of rows a modality gets is a random variable (one or two modalities are drawn per
         index, sgd_alg.py:1912-1927), but a captured graph has fixed launch sizes. Each modality's slot list is therefore
@@ -96,35 +102,33 @@ class _EntityRun:
         write row R of the [R + 1, C] modality matrix — which the shared network never reads — and see a zero gradient row,
         so they add exact zeros to every parameter gradient."""
         pos, order = draw
-        flat = pos.reshape(-1)
+        flat = np.ascontiguousarray(pos.reshape(-1), dtype=np.int8)
         R = flat.size
-        # stable counting sort by modality = the slot lists of the modalities one after the other (a handful of modalities:
-        # one compare + flatnonzero pass each beats a general argsort)
-        lists = [np.flatnonzero(flat == m).astype(np.int32) for m in range(len(order))]
-        counts = np.array([l.size for l in lists], dtype=np.int64)
+        if len(order) > ops.PARTITION_MAX_MODALITIES:
+            raise NotImplementedError(f'{len(order)} modalities on one entity (the slot partition kernel handles '
+                                      f'{ops.PARTITION_MAX_MODALITIES})')
+        counts = np.bincount(flat, minlength=len(order))
         if pad:
             bucket = 64
             while bucket * bucket < 4 * R:
                 bucket *= 2
-            caps = (counts + bucket - 1) // bucket * bucket
-            order_idx = np.full(int(caps.sum()), R, dtype=np.int32)
-            dst = 0
-            for l, cap in zip(lists, caps.tolist()):
-                order_idx[dst:dst + l.size] = l
-                dst += cap
-            counts = caps
-        else:
-            order_idx = np.concatenate(lists) if lists else np.empty(0, np.int32)
-        return order_idx, pos.shape[1], tuple(int(c) for c in counts), tuple(order), R, bool(pad)
+            counts = (counts + bucket - 1) // bucket * bucket
+        return flat, pos.shape[1], tuple(int(c) for c in counts), tuple(order), R, bool(pad)
 
-    def forward(self, idx: torch.Tensor, plan, seed: int, slots: Optional[torch.Tensor] = None):
-        """Launches only (graph-capturable) when ``slots`` — the device copy of plan[0] — is handed in."""
+    def forward(self, idx: torch.Tensor, plan, seed: int, pos_dev: Optional[torch.Tensor] = None):
+        """Launches only (graph-capturable) when ``pos_dev`` — the device copy of plan[0] — is handed in."""
         ent, a, st = self.ent, self.a, ops.stream()
-        order_idx, k, counts, order, R, padded = plan
+        pos_flat, k, counts, order, R, padded = plan
         self.padded = padded
         dev = idx.device
-        if slots is None:
-            slots = torch.from_numpy(order_idx).to(dev, non_blocking=True)
+        if pos_dev is None:
+            pos_dev = torch.from_numpy(pos_flat).to(dev, non_blocking=True)
+        seg = [0]
+        for c in counts:
+            seg.append(seg[-1] + c)
+        slots = a.i32(seg[-1])
+        seg_arr = (ctypes.c_int * len(seg))(*seg)
+        call('sbr_partition_slots', ptr(pos_dev), R, len(counts), ctypes.cast(seg_arr, ctypes.c_void_p), ptr(slots), st)
         entries, tables, offs = [], [], [0]
         for m, c in enumerate(counts):
             if c:
@@ -376,16 +380,17 @@ class FusedTrainStep:
         pb.lab_cached = False
         cached_lab = self._label_cache.get((labels_key, tuple(lab.shape))) if labels_key is not None else None
         if ahead and self._up_stream is None:
-            self._up_stream = torch.cuda.Stream(dev)                 # the loader thread's upload stream
+            self._up_stream = torch.cuda.Stream(dev, priority=-1)    # the loader thread's upload stream
         stream = self._up_stream if ahead else torch.cuda.current_stream(dev)
         parts = [u.reshape(-1), i.reshape(-1), lab.reshape(-1)]
         with torch.cuda.device(dev), torch.cuda.stream(stream):
             if all(t.device.type == 'cpu' for t in parts):
-                # one packed H2D copy: [u | u[0] | i | i[0] | labels | user slots | item slots], 16-byte aligned segments
+                # one packed H2D copy: [u | u[0] | i | i[0] | labels | user modality draw | item modality draw], 16-byte
+                # aligned segments
                 un, inn = parts[0].numpy(), parts[1].numpy()
                 arrs = [np.concatenate([un, un[:1]]), np.concatenate([inn, inn[:1]]),
                         parts[2].numpy() if cached_lab is None else np.empty(0, np.float64),
-                        pb.pu[0] if pb.pu is not None else np.empty(0, np.int32), pb.pi[0]]
+                        pb.pu[0] if pb.pu is not None else np.empty(0, np.int8), pb.pi[0]]
                 offs = [0]
                 for a_ in arrs:
                     offs.append((offs[-1] + a_.nbytes + 15) & ~15)
@@ -422,7 +427,7 @@ class FusedTrainStep:
     @staticmethod
     def _views(packed, layout, has_su):
         v = [packed[o:o + n].view(dt) for (o, n), dt in
-             zip(layout, (torch.int64, torch.int64, torch.float64, torch.int32, torch.int32))]
+             zip(layout, (torch.int64, torch.int64, torch.float64, torch.int8, torch.int8))]
         if not has_su:
             v[3] = None
         return v

@@ -17,6 +17,7 @@ ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'selu': 4}
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 NORM_EPS = 1e-12
+PARTITION_MAX_MODALITIES = 8      # sbr_partition_slots (SBR_PART_MAX in rowops.hip)
 
 
 def act_code(act) -> int:

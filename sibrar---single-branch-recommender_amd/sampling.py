@@ -98,7 +98,9 @@ class DevicePositiveIndex:
         self.device = torch.device(device)
         self.indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(self.device)
         self.indices = torch.from_numpy(csr.indices.astype(np.int32)).to(self.device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        # high priority: the 10-us test kernel must not queue behind the training step's long kernels (the collate thread
+        # blocks on its result two or three times per batch)
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)
 
     def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
         import torch

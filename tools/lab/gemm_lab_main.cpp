@@ -47,6 +47,12 @@ int main(int argc, char** argv) {
     const long ldb = c.mode == 1 ? c.N : c.K;
     float ms = time_ms([&] { sbr_gemm_f32(c.mode, A, c.K, idx, B, ldb, nullptr, nullptr, C, c.N, nullptr, c.M, c.N, c.K, 0, 0, nullptr); });
     printf("%-8s %-28s %9.1f us %8.2f TFLOP/s\n", tag, c.name, ms * 1e3, 2.0 * c.M * c.N * c.K / ms / 1e9);
+    if (c.mode == 0 && c.N <= 1024) {
+      float* bias = dev_rand(c.N, 3);
+      ms = time_ms([&] { sbr_gemm_f32(c.mode, A, c.K, idx, B, ldb, nullptr, bias, C, c.N, nullptr, c.M, c.N, c.K, 1, 0, nullptr); });
+      printf("%-8s %-28s %9.1f us %8.2f TFLOP/s  (+bias, relu)\n", tag, c.name, ms * 1e3, 2.0 * c.M * c.N * c.K / ms / 1e9);
+      hipFree(bias);
+    }
     hipFree(A); hipFree(B); hipFree(C); if (idx) hipFree(idx);
   }
   struct TCase { const char* name; int M, N, K, gather; };
