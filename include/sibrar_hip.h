@@ -57,8 +57,11 @@ int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, 
 /* Stable counting sort of the modality draw: the boolean-mask grouping of the flattened index tensor by sampled modality
  * (algorithms/sgd_alg.py:1934-1957). pos: int8 [R] modality position of every slot; segment m of slots_out
  * ([seg_offsets[m], seg_offsets[m+1]), HOST array of n_mod + 1 offsets, n_mod <= 8) receives the slots of modality m in
- * ascending order, its unused tail (capacity > count) is filled with the sentinel R. */
-int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* seg_offsets, int* slots_out, void* stream);
+ * ascending order, its unused tail (capacity > count) is filled with the sentinel R. workspace: device scratch of
+ * sbr_partition_slots_workspace(R) bytes (per-chunk histograms). */
+long sbr_partition_slots_workspace(long R);
+int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* seg_offsets, int* slots_out, void* workspace,
+                        long workspace_bytes, void* stream);
 
 /* ---- index plumbing ----------------------------------------------------------------------------------------------------
  * rows_out[j] = rowmap_seg(j)[ idx[slots[j] / k] ] for the concatenated per-modality slot lists (segment s covers

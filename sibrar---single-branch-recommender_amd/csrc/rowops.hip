@@ -46,70 +46,114 @@ extern "C" int sbr_resolve_rows(const long* idx, int k, const int* slots, int n,
 // Stable counting sort of the modality draw (sgd_alg.py:1934-1957 groups the flattened index tensor by sampled modality
 // with boolean masks): slots_out[seg_off[m] + r] = index of the r-th slot (ascending) whose modality is m; the tail of every
 // segment (capacity - count, the padding of a graph-mode plan) is filled with the sentinel slot R.
-// One workgroup of 1024 threads: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk) — contiguous chunks + an
-// exclusive scan over the per-thread counts keep the order stable. R is ~1e5: the kernel is latency-sized (~20 us).
+// Two launches: (1) per-block histograms of contiguous 4096-slot chunks, (2) every block adds up the histograms in front of
+// it, ranks its own slots with a block-wide exclusive scan over per-thread counts (thread t owns 16 consecutive slots, so the
+// order stays ascending) and writes them; the padding tails are filled by all blocks together.
 // ---------------------------------------------------------------------------------------------------------------
 #define SBR_PART_MAX 8
+#define PART_EPT 16
+#define PART_CHUNK (256 * PART_EPT)
 struct PartSeg { int n_mod; int offs[SBR_PART_MAX + 1]; };
 
-__global__ __launch_bounds__(1024) void partition_slots_kernel(const signed char* __restrict__ pos, long R, PartSeg sg,
-                                                               int* __restrict__ slots_out) {
-  __shared__ int cnt[SBR_PART_MAX][1024];
-  const int t = threadIdx.x;
-  const long total = sg.offs[sg.n_mod];
-  for (long e = t; e < total; e += 1024) slots_out[e] = (int)R;
-  const long chunk = (R + 1023) / 1024;
-  const long lo = t * chunk, hi = (lo + chunk < R) ? lo + chunk : R;
+__global__ __launch_bounds__(256) void partition_count_kernel(const signed char* __restrict__ pos, long R, int n_mod,
+                                                              int* __restrict__ hist) {
+  __shared__ int h[SBR_PART_MAX];
+  if (threadIdx.x < SBR_PART_MAX) h[threadIdx.x] = 0;
+  __syncthreads();
+  const long lo = (long)blockIdx.x * PART_CHUNK + threadIdx.x * PART_EPT;
   int local[SBR_PART_MAX];
 #pragma unroll
   for (int m = 0; m < SBR_PART_MAX; ++m) local[m] = 0;
-  for (long e = lo; e < hi; ++e) {
-    const int m = pos[e];
+#pragma unroll
+  for (int e = 0; e < PART_EPT; ++e) {
+    const int m = (lo + e < R) ? pos[lo + e] : -1;
 #pragma unroll
     for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (m == q);
   }
 #pragma unroll
-  for (int m = 0; m < SBR_PART_MAX; ++m) cnt[m][t] = local[m];
+  for (int m = 0; m < SBR_PART_MAX; ++m) {
+    const int s = (int)sbr_wave_sum((float)local[m]);       // <= 1024 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0 && m < n_mod) atomicAdd(&h[m], s);
+  }
   __syncthreads();
-  // exclusive scan of each modality's 1024 counts: wave w scans modality w, w + 16, ... (16 values per lane + wave scan)
-  const int lane = t & 63, wave = t >> 6;
-  for (int m = wave; m < sg.n_mod; m += 16) {   // 16 waves, at most 8 modalities: one wave each
-    int v[16], s = 0;
+  if (threadIdx.x < SBR_PART_MAX) hist[blockIdx.x * SBR_PART_MAX + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void partition_scatter_kernel(const signed char* __restrict__ pos, long R, PartSeg sg,
+                                                                const int* __restrict__ hist, int* __restrict__ slots_out) {
+  __shared__ int before[SBR_PART_MAX], total[SBR_PART_MAX];
+  __shared__ int wave_tot[SBR_PART_MAX][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < SBR_PART_MAX) {
+    int bsum = 0, tsum = 0;
+    for (int b = 0; b < (int)gridDim.x; ++b) {
+      const int v = hist[b * SBR_PART_MAX + t];
+      if (b < (int)blockIdx.x) bsum += v;
+      tsum += v;
+    }
+    before[t] = bsum;
+    total[t] = tsum;
+  }
+  const long lo = (long)blockIdx.x * PART_CHUNK + t * PART_EPT;
+  signed char mine[PART_EPT];
+  int local[SBR_PART_MAX];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { v[i] = cnt[m][lane * 16 + i]; s += v[i]; }
-    int incl = s;
+  for (int m = 0; m < SBR_PART_MAX; ++m) local[m] = 0;
+#pragma unroll
+  for (int e = 0; e < PART_EPT; ++e) {
+    mine[e] = (lo + e < R) ? pos[lo + e] : (signed char)-1;
+#pragma unroll
+    for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (mine[e] == q);
+  }
+  // exclusive scan of the per-thread counts over the block, per modality: wave scan + wave totals
+  int excl[SBR_PART_MAX];
+#pragma unroll
+  for (int m = 0; m < SBR_PART_MAX; ++m) {
+    int incl = local[m];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int up = __shfl_up(incl, o, 64);
       if (lane >= o) incl += up;
     }
-    int run = incl - s;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { cnt[m][lane * 16 + i] = run; run += v[i]; }
+    excl[m] = incl - local[m];
+    if (lane == 63) wave_tot[m][wave] = incl;
   }
   __syncthreads();
-  int w[SBR_PART_MAX];
 #pragma unroll
-  for (int m = 0; m < SBR_PART_MAX; ++m) w[m] = (m < sg.n_mod) ? sg.offs[m] + cnt[m][t] : 0;
-  __syncthreads();               // the fill above and the writes below touch the same array: order them
-  for (long e = lo; e < hi; ++e) {
-    const int m = pos[e];
+  for (int m = 0; m < SBR_PART_MAX; ++m) {
+    int w = (m < sg.n_mod ? sg.offs[m] : 0) + before[m] + excl[m];
+    for (int k = 0; k < wave; ++k) w += wave_tot[m][k];
+    excl[m] = w;                                              // first output position of this thread for modality m
+  }
+#pragma unroll
+  for (int e = 0; e < PART_EPT; ++e) {
 #pragma unroll
     for (int q = 0; q < SBR_PART_MAX; ++q)
-      if (m == q) slots_out[w[q]++] = (int)e;
+      if (mine[e] == q) slots_out[excl[q]++] = (int)(lo + e);
+  }
+  // padding tails [offs[m] + total[m], offs[m+1]) <- R, shared by all blocks
+  for (int m = 0; m < sg.n_mod; ++m) {
+    const int beg = sg.offs[m] + total[m], end = sg.offs[m + 1];
+    for (int e = beg + blockIdx.x * 256 + t; e < end; e += gridDim.x * 256) slots_out[e] = (int)R;
   }
 }
 
+extern "C" long sbr_partition_slots_workspace(long R) { return (long)sbr_cdiv(R > 0 ? R : 1, PART_CHUNK) * SBR_PART_MAX * (long)sizeof(int); }
+
 extern "C" int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* seg_offsets, int* slots_out,
-                                   void* stream) {
+                                   void* workspace, long workspace_bytes, void* stream) {
   SBR_REQUIRE(n_mod >= 1 && n_mod <= SBR_PART_MAX, "sbr_partition_slots: n_mod %d out of range", n_mod);
   SBR_REQUIRE(R >= 0 && R < 2147483647L, "sbr_partition_slots: R out of range");
   SBR_REQUIRE(pos && seg_offsets && slots_out, "sbr_partition_slots: null operand");
+  SBR_REQUIRE(workspace && workspace_bytes >= sbr_partition_slots_workspace(R), "sbr_partition_slots: workspace too small");
   PartSeg sg;
   sg.n_mod = n_mod;
   for (int i = 0; i <= n_mod; ++i) sg.offs[i] = seg_offsets[i];
   if (sg.offs[n_mod] == 0) return SBR_OK;
-  partition_slots_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pos, R, sg, slots_out);
+  const int nb = sbr_cdiv(R > 0 ? R : 1, PART_CHUNK);
+  hipStream_t s = (hipStream_t)stream;
+  partition_count_kernel<<<nb, 256, 0, s>>>(pos, R, n_mod, (int*)workspace);
+  partition_scatter_kernel<<<nb, 256, 0, s>>>(pos, R, sg, (const int*)workspace, slots_out);
   SBR_CHECK_LAUNCH("sbr_partition_slots");
   return SBR_OK;
 }

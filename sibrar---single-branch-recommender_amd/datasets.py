@@ -10,6 +10,7 @@
 from __future__ import annotations
 
 import atexit
+import os
 import weakref
 from types import SimpleNamespace
 from typing import Dict, Optional, Sequence
@@ -192,7 +193,10 @@ class NegativeSamplingDataLoader:
 
         out = queue.Queue(maxsize=self.prefetch)
         threads = []
-        if self.prepare_fn is None:
+        two_stage = self.batch_size * (1 + self.n_neg) >= 32768 if os.environ.get('SBR_LOADER_STAGES') is None \
+            else os.environ['SBR_LOADER_STAGES'] == '2'
+        if self.prepare_fn is None or not two_stage:
+            # small batches: every numpy call is too short to release the GIL, a second producer thread only adds hand-offs
             threads.append(threading.Thread(target=stage, args=(self._produce(), out, lambda b: b), daemon=True))
         else:
             # two pipeline stages, one thread each: collate (global numpy stream) -> prepare (entity streams, uploads). Each

@@ -365,3 +365,33 @@ def test_csr_projector_long_tailed_rows(C, act):
              n, C, ops.stream())
         ref_dw = dz.t() @ d[rows.long()]                  # [C, n_cols]
         close(dwt.cpu().t(), ref_dw, rtol=1e-4, atol=1e-5, what=f'csr dW vals={use_vals}', norm_rtol=1e-5)
+
+
+@pytest.mark.parametrize('R,n_mod,pad', [(1, 1, 0), (24, 2, 64), (4096, 3, 0), (4097, 2, 128), (90112, 2, 1024), (180224, 8, 0)])
+def test_partition_slots_is_a_stable_counting_sort(R, n_mod, pad):
+    """sbr_partition_slots == the stable argsort of the modality draw (the boolean-mask grouping of sgd_alg.py:1934-1957), with
+    every segment padded to its capacity by the sentinel R."""
+    import ctypes, importlib
+    mod = S()
+    _lib = importlib.import_module(mod.ops.__name__.rsplit('.', 1)[0] + '._lib')
+    call, ptr, ops = _lib.call, _lib.ptr, mod.ops
+    rng = np.random.default_rng(R + n_mod)
+    pos = rng.integers(0, n_mod, size=R).astype(np.int8)
+    if n_mod > 2:
+        pos[pos == 1] = 0                                   # an empty modality in between
+    counts = np.bincount(pos, minlength=n_mod)
+    caps = (counts + pad - 1) // pad * pad if pad else counts
+    seg = np.concatenate([[0], np.cumsum(caps)]).astype(np.int32)
+    want = np.full(int(seg[-1]), R, dtype=np.int32)
+    order = np.argsort(pos, kind='stable').astype(np.int32)
+    src = 0
+    for m in range(n_mod):
+        want[seg[m]:seg[m] + counts[m]] = order[src:src + counts[m]]
+        src += counts[m]
+    pos_d = torch.from_numpy(pos).to(DEV)
+    out = torch.full((max(int(seg[-1]), 1),), -7, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(mod.lib().sbr_partition_slots_workspace(R) // 4 + 8, dtype=torch.int32, device=DEV)
+    seg_arr = (ctypes.c_int * len(seg))(*seg.tolist())
+    call('sbr_partition_slots', ptr(pos_d), R, n_mod, ctypes.cast(seg_arr, ctypes.c_void_p), ptr(out), ptr(ws), ws.numel() * 4,
+         ops.stream())
+    assert np.array_equal(out.cpu().numpy()[:int(seg[-1])], want)
