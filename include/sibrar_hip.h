@@ -54,6 +54,12 @@ long sbr_gemm_tn_f32_workspace(int M, int N, int K);
 int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C, long ldc,
                     int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
 
+/* HOST function (no device work): numpy's legacy `np.random.randint(0, high, size=n)` on a caller-owned MT19937 state
+ * (key[624] + position from np.random.get_state(), advanced in place) — the draws of the default negative-sampling collate
+ * (data/dataloader.py:154-198, np.random.choice(items_in_split, n) on the global RandomState). Bit-identical values and final
+ * state for high - 1 < 2^32. */
+int sbr_host_mt19937_randint(unsigned int* key, int* pos, long high, long n, long* out);
+
 /* Stable counting sort of the modality draw: the boolean-mask grouping of the flattened index tensor by sampled modality
  * (algorithms/sgd_alg.py:1934-1957). pos: int8 [R] modality position of every slot; segment m of slots_out
  * ([seg_offsets[m], seg_offsets[m+1]), HOST array of n_mod + 1 offsets, n_mod <= 8) receives the slots of modality m in
@@ -102,7 +108,8 @@ int sbr_csr_project_bwd(const long* indptr, const int* indices, const float* val
 /* dZ[j, :] = dY[ii(j), :] * act'(Y[ii(j), :]) — autograd of the activations of modules/polylinear.py:63-72 */
 int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz, long n, int C,
                         int act, void* stream);
-/* out[c] = sum_j X[j, c] (bias gradients). workspace: C doubles. */
+/* out[c] = sum_j X[j, c] (bias gradients). workspace: 17*C doubles (totals + 16 replicas that spread the per-block atomics);
+ * it must be ZERO on first use and every call leaves it zeroed again (no memset per call). */
 int sbr_colsum(const float* X, long ld, long n, int C, float* out, double* workspace, void* stream);
 
 /* F.normalize(p=2, dim=-1, eps) — algorithms/sgd_alg.py:1873-1874 */
@@ -125,7 +132,8 @@ int sbr_bias_score_fwd(const float* user_bias, const float* item_bias, const flo
                        float* out, long B, int N, void* stream);
 
 /* ---- BatchNorm1d (+ fused activation) — modules/polylinear.py:61,68; algorithms/sgd_alg.py:1837 ---------------------------
- * ws: 2*D doubles of workspace. running_mean/var/num_batches_tracked may be NULL. */
+ * ws: 34*D doubles of workspace (2*D totals + 16 replicas that spread the per-block atomics); ZERO on first use, every call
+ * leaves the replicas zeroed again (forward and backward may share one workspace). running_mean/var/num_batches_tracked may be NULL. */
 int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias, float* running_mean,
                      float* running_var, long* num_batches_tracked, float* save_mean, float* save_rstd, double* ws, float eps,
                      float momentum, int act, void* stream);
@@ -152,6 +160,11 @@ int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, int N, int 
                     void* stream);
 int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, int N, int D, float tau, double scale,
                     const float* grad_out, float* dA, float* dB, long ldg, void* stream);
+
+/* out3 = (rec + reg, rec, reg), reg = w_a * reg_a + w_b * reg_b: the total loss of train/trainer.py:213-216 from the device-side
+ * loss scalars (reg_a / reg_b may be NULL). */
+int sbr_pack_losses(const double* rec, const double* reg_a, double w_a, const double* reg_b, double w_b, double* out3,
+                    void* stream);
 
 /* The same loss for groups of any size (in-batch contrast of B user rows, sgd_alg.py:1994-2002): the N x N logits go
  * through the fp32 MFMA GEMMs (sbr_gemm_f32 / sbr_gemm_tn_f32) instead of LDS. workspace: sbr_infonce_gemm_workspace(N, D)

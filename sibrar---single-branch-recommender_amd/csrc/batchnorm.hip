@@ -29,15 +29,23 @@ __global__ void bn_stats_kernel(const float* __restrict__ X, long n, int D, doub
   }
 }
 
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict__ X, long n, int D, double* __restrict__ ws) {
+  sbr_col_reduce<2>(n, D, ws, [&](long j, int cg, float4* v) {
+    const float4 x = *reinterpret_cast<const float4*>(X + j * D + 4 * cg);
+    v[0] = x;
+    v[1] = make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
+  });
+}
+
 // one thread per column: batch mean / rstd, running-stat update
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, long n, int D, float eps, float momentum,
+__global__ void bn_finalize_kernel(double* __restrict__ ws, long n, int D, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long* __restrict__ num_batches) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches) num_batches[0] += 1;
   if (c >= D) return;
-  const double m = ws[c] / (double)n;
-  double var = ws[D + c] / (double)n - m * m;
+  const double m = sbr_colred_take(ws, 2 * D, c) / (double)n;                 // also re-zeroes the replicas
+  double var = sbr_colred_take(ws, 2 * D, D + c) / (double)n - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -74,17 +82,21 @@ static int grid1d(long total) {
   return b > 4096 ? 4096 : (b < 1 ? 1 : b);
 }
 
-// workspace ws: 2*D doubles
+// workspace ws: 34*D doubles (2*D totals + 16 replicas, see sbr_col_reduce in common.h), ZERO on first use; every call
+// leaves the replica part zeroed again (no memset per call)
 extern "C" int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
                                 float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
                                 float* save_rstd, double* ws, float eps, float momentum, int act, void* stream) {
   SBR_REQUIRE(X && Y && weight && bias && save_mean && save_rstd && ws, "sbr_bn_train_fwd: null operand");
   SBR_REQUIRE(n >= 1, "sbr_bn_train_fwd: BatchNorm needs at least one row");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * D, s) != hipSuccess) { sbr_set_error("sbr_bn_train_fwd: memset failed"); return SBR_ERR_HIP; }
-  int bx = sbr_cdiv(n, 64);
-  if (bx > 512) bx = 512;
-  bn_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(X, n, D, ws);
+  if (sbr_col_reduce_ok(X, D, D)) {
+    bn_stats4_kernel<<<sbr_col_reduce_blocks(n, D), 256, 0, s>>>(X, n, D, ws);
+  } else {                       // generic path: atomics straight into replica 1
+    int bx = sbr_cdiv(n, 64);
+    if (bx > 512) bx = 512;
+    bn_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(X, n, D, ws + 2 * D);
+  }
   SBR_CHECK_LAUNCH("sbr_bn_train_fwd/stats");
   bn_finalize_kernel<<<sbr_cdiv(D, 256), 256, 0, s>>>(ws, n, D, eps, momentum, save_mean, save_rstd, running_mean,
                                                       running_var, num_batches_tracked);
@@ -131,6 +143,25 @@ __global__ void bn_bwd_stats_kernel(const float* __restrict__ dY, const float* _
   }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                            const float* __restrict__ X, long n, int D,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int act, double* __restrict__ ws) {
+  const int cg0 = threadIdx.x % (D >> 2);
+  const float4 m = *reinterpret_cast<const float4*>(mean + 4 * cg0), r = *reinterpret_cast<const float4*>(rstd + 4 * cg0);
+  sbr_col_reduce<2>(n, D, ws, [&](long j, int cg, float4* v) {
+    const long e = j * D + 4 * cg;
+    const float4 g = *reinterpret_cast<const float4*>(dY + e), y = *reinterpret_cast<const float4*>(Y + e),
+                 x = *reinterpret_cast<const float4*>(X + e);
+    float4 dz;
+    dz.x = g.x * sbr_act_grad_from_out(y.x, act); dz.y = g.y * sbr_act_grad_from_out(y.y, act);
+    dz.z = g.z * sbr_act_grad_from_out(y.z, act); dz.w = g.w * sbr_act_grad_from_out(y.w, act);
+    v[0] = dz;
+    v[1] = make_float4(dz.x * ((x.x - m.x) * r.x), dz.y * ((x.y - m.y) * r.y), dz.z * ((x.z - m.z) * r.z),
+                       dz.w * ((x.w - m.w) * r.w));
+  });
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ X,
                                     float* __restrict__ dX, long n, int D, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ w, int act,
@@ -156,10 +187,14 @@ extern "C" int sbr_bn_train_bwd(const float* dY, const float* Y, const float* X,
   SBR_REQUIRE(dY && Y && X && dX && weight && save_mean && save_rstd && dWeight && dBias && ws, "sbr_bn_train_bwd: null operand");
   SBR_REQUIRE(n >= 1, "sbr_bn_train_bwd: empty batch");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * D, s) != hipSuccess) { sbr_set_error("sbr_bn_train_bwd: memset failed"); return SBR_ERR_HIP; }
-  int bx = sbr_cdiv(n, 64);
-  if (bx > 512) bx = 512;
-  bn_bwd_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(dY, Y, X, n, D, save_mean, save_rstd, act, ws);
+  if (sbr_col_reduce_ok(X, D, D) && ((((uintptr_t)dY) | ((uintptr_t)Y) | ((uintptr_t)save_mean) | ((uintptr_t)save_rstd)) & 15) == 0) {
+    bn_bwd_stats4_kernel<<<sbr_col_reduce_blocks(n, D), 256, 0, s>>>(dY, Y, X, n, D, save_mean, save_rstd, act, ws);
+  } else {                       // generic path: atomics straight into replica 1
+    int bx = sbr_cdiv(n, 64);
+    if (bx > 512) bx = 512;
+    bn_bwd_stats_kernel<<<dim3(bx, sbr_cdiv(D, 64)), 256, 0, s>>>(dY, Y, X, n, D, save_mean, save_rstd, act, ws + 2 * D);
+  }
+  sbr_colred_final_kernel<<<sbr_cdiv(2 * D, 256), 256, 0, s>>>(ws, 2 * D);
   SBR_CHECK_LAUNCH("sbr_bn_train_bwd/stats");
   bn_bwd_apply_kernel<<<grid1d(n * D), 256, 0, s>>>(dY, Y, X, dX, n, D, save_mean, save_rstd, weight, act, ws, dWeight, dBias);
   SBR_CHECK_LAUNCH("sbr_bn_train_bwd/apply");

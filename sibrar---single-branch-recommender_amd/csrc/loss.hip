@@ -324,3 +324,24 @@ extern "C" int sbr_infonce_gemm_bwd(const float* A, const float* B, long ld, lon
   }
   return SBR_OK;
 }
+
+
+// out[0] = rec + reg, out[1] = rec, out[2] = reg with reg = w_a * reg_a + w_b * reg_b (trainer.py:213-216: total loss = rec loss +
+// weighted regularisation losses). One tiny launch instead of five elementwise ones; null reg pointers count as zero.
+__global__ void pack_losses_kernel(const double* __restrict__ rec, const double* __restrict__ reg_a, double w_a,
+                                   const double* __restrict__ reg_b, double w_b, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double reg = (reg_a ? w_a * reg_a[0] : 0.0) + (reg_b ? w_b * reg_b[0] : 0.0);
+    out[0] = rec[0] + reg;
+    out[1] = rec[0];
+    out[2] = reg;
+  }
+}
+
+extern "C" int sbr_pack_losses(const double* rec, const double* reg_a, double w_a, const double* reg_b, double w_b, double* out3,
+                               void* stream) {
+  SBR_REQUIRE(rec && out3, "sbr_pack_losses: null operand");
+  pack_losses_kernel<<<1, 64, 0, (hipStream_t)stream>>>(rec, reg_a, w_a, reg_b, w_b, out3);
+  SBR_CHECK_LAUNCH("sbr_pack_losses");
+  return SBR_OK;
+}

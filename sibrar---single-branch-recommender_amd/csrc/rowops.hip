@@ -442,10 +442,34 @@ __global__ void act_grad_gather_kernel(const float* __restrict__ dY, const float
   }
 }
 
+__global__ void act_grad_gather4_kernel(const float* __restrict__ dY, const float* __restrict__ Y, long ld,
+                                        const int* __restrict__ in_idx, float* __restrict__ dZ, long ldz, long n, int C4,
+                                        int act) {
+  const long total = n * C4;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long j = e / C4;
+    const int c = (int)(e - j * C4) * 4;
+    const long i = (in_idx ? (long)in_idx[j] : j) * ld + c;
+    const float4 g = *reinterpret_cast<const float4*>(dY + i);
+    const float4 y = *reinterpret_cast<const float4*>(Y + i);
+    float4 o;
+    o.x = g.x * sbr_act_grad_from_out(y.x, act); o.y = g.y * sbr_act_grad_from_out(y.y, act);
+    o.z = g.z * sbr_act_grad_from_out(y.z, act); o.w = g.w * sbr_act_grad_from_out(y.w, act);
+    *reinterpret_cast<float4*>(dZ + j * ldz + c) = o;
+  }
+}
+
 extern "C" int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz,
                                    long n, int C, int act, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(dY && Y && dZ, "sbr_act_grad_gather: null operand");
+  if ((C & 3) == 0 && (ld & 3) == 0 && (ldz & 3) == 0 && ((((uintptr_t)dY) | ((uintptr_t)Y) | ((uintptr_t)dZ)) & 15) == 0) {
+    int blocks4 = sbr_cdiv(n * (C / 4), 256);
+    if (blocks4 > 8192) blocks4 = 8192;
+    act_grad_gather4_kernel<<<blocks4, 256, 0, (hipStream_t)stream>>>(dY, Y, ld, in_idx, dZ, ldz, n, C / 4, act);
+    SBR_CHECK_LAUNCH("sbr_act_grad_gather");
+    return SBR_OK;
+  }
   int blocks = sbr_cdiv(n * C, 256);
   if (blocks > 4096) blocks = 4096;
   act_grad_gather_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dY, Y, ld, in_idx, dZ, ldz, n, C, act);
@@ -475,18 +499,29 @@ __global__ void d2f_kernel(const double* __restrict__ a, float* __restrict__ out
 }
 
 // workspace: C doubles, zeroed by this call
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ X, long ld, long n, int C,
+                                                      double* __restrict__ acc) {
+  sbr_col_reduce<1>(n, C, acc, [&](long j, int cg, float4* v) { v[0] = *reinterpret_cast<const float4*>(X + j * ld + 4 * cg); });
+}
+
+__global__ void colsum_final_kernel(double* __restrict__ ws, int C, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) out[i] = (float)sbr_colred_take(ws, C, i);
+}
+
+// workspace: 17*C doubles, ZERO on first use; every call leaves it zeroed again (no memset per call)
 extern "C" int sbr_colsum(const float* X, long ld, long n, int C, float* out, double* workspace, void* stream) {
   SBR_REQUIRE(out && workspace, "sbr_colsum: null operand");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, sizeof(double) * C, s) != hipSuccess) { sbr_set_error("sbr_colsum: memset failed"); return SBR_ERR_HIP; }
-  if (n > 0) {
+  if (n > 0 && sbr_col_reduce_ok(X, ld, C)) {
+    colsum4_kernel<<<sbr_col_reduce_blocks(n, C), 256, 0, s>>>(X, ld, n, C, workspace);
+  } else if (n > 0) {          // generic path: atomics straight into replica 1
     int bx = sbr_cdiv(n, 64);
     if (bx > 512) bx = 512;
-    colsum_kernel<<<dim3(bx, sbr_cdiv(C, 64)), 256, 0, s>>>(X, ld, n, C, workspace);
-    SBR_CHECK_LAUNCH("sbr_colsum");
+    colsum_kernel<<<dim3(bx, sbr_cdiv(C, 64)), 256, 0, s>>>(X, ld, n, C, workspace + C);
   }
-  d2f_kernel<<<sbr_cdiv(C, 256), 256, 0, s>>>(workspace, out, C);
-  SBR_CHECK_LAUNCH("sbr_colsum/d2f");
+  colsum_final_kernel<<<sbr_cdiv(C, 256), 256, 0, s>>>(workspace, C, out);
+  SBR_CHECK_LAUNCH("sbr_colsum");
   return SBR_OK;
 }
 
@@ -669,9 +704,40 @@ __global__ void score_dot_bwd_kernel(const float* __restrict__ G, const float* _
   }
 }
 
+// D % 4 == 0, D <= 256: D/4 lanes per slot read one float4 each, 64 / (D/4) slots per wave (power-of-two groups)
+template <int LPS>
+__global__ void score_dot_fwd4_kernel(const float* __restrict__ U, const float* __restrict__ I, float* __restrict__ out,
+                                      long B, int N, int D) {
+  constexpr int SPW = 64 / LPS;                               // slots per wave
+  const int lane = threadIdx.x & 63, l = lane % LPS, sub = lane / LPS;
+  const long wave = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long s = wave * SPW + sub;
+  float acc = 0.f;
+  if (s < B * N && 4 * l < D) {
+    const long b = s / N;
+    const float4 u = *reinterpret_cast<const float4*>(U + b * D + 4 * l);
+    const float4 v = *reinterpret_cast<const float4*>(I + s * D + 4 * l);
+    acc = u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+  }
+#pragma unroll
+  for (int o = LPS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (l == 0 && s < B * N) out[s] = acc;
+}
+
 extern "C" int sbr_score_dot_fwd(const float* U, const float* I, float* out, long B, int N, int D, void* stream) {
   if (B * N == 0) return SBR_OK;
   SBR_REQUIRE(U && I && out, "sbr_score_dot_fwd: null operand");
+  if ((D & 3) == 0 && D <= 256 && ((((uintptr_t)U) | ((uintptr_t)I)) & 15) == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    const int lps = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
+    const long waves = sbr_cdiv(B * N, 64 / lps);
+    const int blocks = sbr_cdiv(waves, 4);
+    if (lps == 16) score_dot_fwd4_kernel<16><<<blocks, 256, 0, s>>>(U, I, out, B, N, D);
+    else if (lps == 32) score_dot_fwd4_kernel<32><<<blocks, 256, 0, s>>>(U, I, out, B, N, D);
+    else score_dot_fwd4_kernel<64><<<blocks, 256, 0, s>>>(U, I, out, B, N, D);
+    SBR_CHECK_LAUNCH("sbr_score_dot_fwd");
+    return SBR_OK;
+  }
   score_dot_fwd_kernel<<<sbr_cdiv(B * N, 4), 256, 0, (hipStream_t)stream>>>(U, I, out, B, N, D);
   SBR_CHECK_LAUNCH("sbr_score_dot_fwd");
   return SBR_OK;

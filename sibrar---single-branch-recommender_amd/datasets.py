@@ -239,19 +239,21 @@ class NegativeSamplingDataLoader:
     def _produce(self, prepare: bool = True):
         n = len(self.rows)
         order = loader_epoch_order(n) if self.shuffle else np.arange(n)
+        # the epoch's (user, item) pairs in visiting order, gathered ONCE: per batch a contiguous slice instead of two random
+        # gathers over the whole interaction list
+        rows_e, cols_e = (self.rows[order], self.cols[order]) if self.shuffle else (self.rows, self.cols)
         local = self.dp_sampling == 'local' and self.world > 1
         for b in range(len(self)):
             if local:       # rank r owns the r-th contiguous chunk of every global step (an incomplete last global step is dropped)
                 lo = (b * self.world + self.rank) * self.batch_size
-                sel = order[lo:lo + self.batch_size]
             else:
-                sel = order[b * self.batch_size:(b + 1) * self.batch_size]
+                lo = b * self.batch_size
+            bu, bi = rows_e[lo:lo + self.batch_size], cols_e[lo:lo + self.batch_size]
             if self.strategy == 'uniform_recbole':
-                u, i, l = recbole_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.items_in_split,
-                                                   self.positives, self._identity_items)
+                u, i, l = recbole_negative_collate(bu, bi, self.n_neg, self.dataset.items_in_split, self.positives,
+                                                   self._identity_items)
             else:
-                u, i, l = uniform_negative_collate(self.rows[sel], self.cols[sel], self.n_neg, self.dataset.n_items,
-                                                   self.positives)
+                u, i, l = uniform_negative_collate(bu, bi, self.n_neg, self.dataset.n_items, self.positives)
             # data parallel: every rank consumes the same global streams and keeps its slice (parallel.shard_batch)
             if self.world > 1 and not local:
                 u, i, l = u[self.rank::self.world], i[self.rank::self.world], l[self.rank::self.world]

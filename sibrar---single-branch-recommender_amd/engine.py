@@ -88,6 +88,7 @@ class _EntityRun:
         self.normalize = cfg.normalize_single_branch_input
         self.reg = ent._reg_type != EmbeddingRegularizationType.NoRegularization
         self.tau, self.reg_w = float(cfg.regularization_temperature), float(cfg.regularization_weight)
+        self._ws = {}
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def plan(self, draw: Tuple[np.ndarray, list], pad: bool = False):
@@ -190,10 +191,17 @@ class _EntityRun:
         call('sbr_aggregate_fwd', ptr(x), ptr(out), ptr(self.arg), S, k, self.D, ent._agg_mode, st)
         return out
 
+    def _bn_ws(self, bn, D):
+        """Persistent column-reduction workspace of one BatchNorm (zero on first use, left zeroed by every kernel pair)."""
+        ws = self._ws.get(id(bn))
+        if ws is None:
+            ws = self._ws[id(bn)] = torch.zeros(ops.COLRED_WS_FACTOR * 2 * D, device=bn.weight.device, dtype=torch.float64)
+        return ws
+
     def _bn_fwd(self, bn, x, act):
         a, st = self.a, ops.stream()
         n, D = x.shape
-        y, mean, rstd, ws = a.f32(n, D), a.f32(D), a.f32(D), a.f64(2 * D)
+        y, mean, rstd, ws = a.f32(n, D), a.f32(D), a.f32(D), self._bn_ws(bn, D)
         call('sbr_bn_train_fwd', ptr(x), ptr(y), n, D, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
              ptr(bn.num_batches_tracked), ptr(mean), ptr(rstd), ptr(ws), ops.BN_EPS, ops.BN_MOMENTUM, act, st)
         return y, mean, rstd
@@ -201,7 +209,7 @@ class _EntityRun:
     def _bn_bwd(self, bn, dy, y, x, mean, rstd, act):
         a, st = self.a, ops.stream()
         n, D = x.shape
-        dx, ws = a.f32(n, D), a.f64(2 * D)
+        dx, ws = a.f32(n, D), self._bn_ws(bn, D)
         call('sbr_bn_train_bwd', ptr(dy), ptr(y), ptr(x), ptr(dx), n, D, ptr(bn.weight), ptr(mean), ptr(rstd),
              ptr(_grad_of(bn.weight)), ptr(_grad_of(bn.bias)), ptr(ws), act, st)
         return dx
@@ -354,12 +362,11 @@ class FusedTrainStep:
         call('sbr_score_dot_bwd', ptr(dlog), ptr(ur), ptr(ir), ptr(dU), ptr(dI), B, N, D, st)
         self.item.backward(dI, self.one32)
         self.user.backward(dU, self.one32)
-        reg = torch.zeros((), device=u.device, dtype=torch.float64)
-        for side in (self.user, self.item):
-            if side.reg_loss is not None:
-                reg = reg + side.reg_loss * side.reg_w
-        rec = loss.clone()
-        return rec + reg, rec, reg
+        out = a.f64(3)                                               # (total, rec, reg)
+        ru, ri = self.user.reg_loss, self.item.reg_loss
+        call('sbr_pack_losses', ptr(loss), ptr(ru), float(getattr(self.user, 'reg_w', 0.0)), ptr(ri),
+             float(getattr(self.item, 'reg_w', 0.0)), ptr(out), st)
+        return out
 
     # ---- host side of a step: draw, plan, uploads (may run on the loader thread) ---------------------------------------------
     def prepare(self, u_idxs, i_idxs, labels, draws=None, ahead: bool = True, labels_key=None) -> 'PreparedBatch':
@@ -464,8 +471,8 @@ class FusedTrainStep:
         # thread_local: the loader thread keeps issuing its own copies / kernels on its streams meanwhile
         with torch.cuda.graph(cs.graph, capture_error_mode='thread_local'):
             with pin_stream():
-                cs.out = torch.stack(self._fwd_bwd(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi,
-                                                   cs.su, cs.si, 0))
+                cs.out = self._fwd_bwd(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi,
+                                       cs.su, cs.si, 0)
         self._graphs[key] = cs
         return cs
 
@@ -510,7 +517,8 @@ class FusedTrainStep:
                     self.n_replays += 1
                     out = cs.out.clone().unbind(0)
             if out is None:
-                out = self._fwd_bwd(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si, seed)
+                out = self._fwd_bwd(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si,
+                                    seed).clone().unbind(0)
             # ---- reduce + update
             if parallel.is_distributed():
                 parallel.all_reduce_flat_(self.opt.fp.grad)

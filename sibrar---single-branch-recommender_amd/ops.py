@@ -18,6 +18,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 NORM_EPS = 1e-12
 PARTITION_MAX_MODALITIES = 8      # sbr_partition_slots (SBR_PART_MAX in rowops.hip)
+COLRED_WS_FACTOR = 17             # column-reduction workspaces: totals + SBR_COLRED_REP replicas (common.h)
 
 
 def act_code(act) -> int:
@@ -133,7 +134,7 @@ def colsum(x: torch.Tensor, out=None) -> torch.Tensor:
         out = torch.empty(C, device=x.device, dtype=torch.float32)
     ws = _COLSUM_WS.get((x.device, C))
     if ws is None:
-        ws = _COLSUM_WS[(x.device, C)] = torch.empty(C, device=x.device, dtype=torch.float64)
+        ws = _COLSUM_WS[(x.device, C)] = torch.zeros(COLRED_WS_FACTOR * C, device=x.device, dtype=torch.float64)
     call('sbr_colsum', ptr(x), x.stride(0), n, C, ptr(out), ptr(ws), stream())
     return out
 
@@ -185,7 +186,7 @@ class BatchNormActFn(Function):
         y = torch.empty_like(x)
         mean = torch.empty(D, device=x.device, dtype=torch.float32)
         rstd = torch.empty(D, device=x.device, dtype=torch.float32)
-        ws = torch.empty(2 * D, device=x.device, dtype=torch.float64)
+        ws = torch.zeros(COLRED_WS_FACTOR * 2 * D, device=x.device, dtype=torch.float64)
         call('sbr_bn_train_fwd', ptr(x), ptr(y), n, D, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
              ptr(num_batches_tracked), ptr(mean), ptr(rstd), ptr(ws), BN_EPS, BN_MOMENTUM, act, stream())
         ctx.act = act
@@ -201,7 +202,7 @@ class BatchNormActFn(Function):
         dx = torch.empty_like(x)
         dw = torch.empty(D, device=x.device, dtype=torch.float32)
         db = torch.empty(D, device=x.device, dtype=torch.float32)
-        ws = torch.empty(2 * D, device=x.device, dtype=torch.float64)
+        ws = torch.zeros(COLRED_WS_FACTOR * 2 * D, device=x.device, dtype=torch.float64)
         call('sbr_bn_train_bwd', ptr(dy), ptr(y), ptr(x), ptr(dx), n, D, ptr(weight), ptr(mean), ptr(rstd), ptr(dw), ptr(db),
              ptr(ws), ctx.act, stream())
         return dx, dw, db, None, None, None, None

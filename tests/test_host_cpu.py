@@ -220,3 +220,19 @@ def test_two_rank_gloo_data_parallel_and_item_sharding(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f'rank {r} failed:\n{o}'
         assert f'rank {r} ok' in o
+
+
+@pytest.mark.parametrize('high,n', [(50000, 81920), (1, 4000), (2, 5000), (3299, 2816), (65536, 4096), (65537, 4097), (2 ** 32, 3000)])
+def test_native_legacy_randint_matches_numpy_stream(high, n):
+    """csrc/host_rng.hip (host code, no GPU): same values as np.random.randint(0, high, n) on the global legacy generator AND the
+    same generator state afterwards (the draws that follow are identical)."""
+    from importlib import import_module
+    import sibrar_amd
+    sampling = import_module(sibrar_amd.ops.__name__.rsplit('.', 1)[0] + '.sampling')
+    np.random.seed(high % 1000 + n)
+    np.random.randint(0, 7, size=n % 601)                    # arbitrary position inside the 624-word state
+    st = np.random.get_state()
+    want, after = np.random.randint(0, high, size=n), np.random.randint(0, 1000, size=9)
+    np.random.set_state(st)
+    got, after2 = sampling.legacy_randint(high, n), np.random.randint(0, 1000, size=9)
+    assert got.dtype == want.dtype and np.array_equal(got, want) and np.array_equal(after, after2)
