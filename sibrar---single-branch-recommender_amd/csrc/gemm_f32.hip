@@ -370,10 +370,12 @@ extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx
 // ---- TN with a split-K slab reducer ------------------------------------------------------------------------------------
 static int tn_splits(int M, int N, int K) {
   const int tiles = sbr_cdiv(M, 64) * sbr_cdiv(N, 128);
-  int want = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU
+  // work items (tiles x K ranges) to aim for: 512 for a single-panel dW (128 x 128: 45 us; 768 items 50 us, 1536 items 62 us —
+  // the partial slabs grow with the split count), 1536 once there are many tiles (128 x 768 over 45056 rows: 110 vs 119 us)
+  int want = ((tiles >= 8 ? 1536 : 512) + tiles - 1) / tiles;
   const int max_splits = sbr_cdiv(K, 4 * BK);         // at least 4 slabs of K per workgroup
   int splits = want < max_splits ? want : max_splits;
-  const int min_splits = sbr_cdiv(K, 768);             // the ring kernel stages <= 768 gathered k-row indices per item
+  const int min_splits = sbr_cdiv(K, 512);             // the ring kernel stages <= 512 gathered k-row indices per item
   if (splits < min_splits) splits = min_splits;
   if (getenv("SBR_TN_SPLITS") && atoi(getenv("SBR_TN_SPLITS")) > 0) splits = atoi(getenv("SBR_TN_SPLITS"));   // tuning aid
   return splits < 1 ? 1 : splits;

@@ -13,7 +13,7 @@
 //     is always lane-linear).
 // Operands are addressed in 16-byte chunks; a chunk outside the matrix / K range is fetched from a zero chunk instead, so
 // there is no predicated load anywhere. Eligibility (checked on the host): 16-byte aligned bases and row strides, K % 4 == 0
-// for k-contiguous operands, row counts % 4 == 0 for k-major operands, gathered k-major operands with <= 768 k rows per item.
+// for k-contiguous operands, row counts % 4 == 0 for k-major operands, gathered k-major operands with <= 512 k rows per item.
 //
 // LDS slab images (RK = 32 k per slab):
 //   k-contiguous operand (NT A/B, NN A):  [rows][8 chunks]   position (r, p) holds chunk p ^ ((r >> 1) & 7) of row r
@@ -24,7 +24,7 @@
 #include <stdlib.h>
 
 #define RK 32
-#define RING_IDX_CAP 768
+#define RING_IDX_CAP 512
 #define RING_BIAS_CAP 1024
 
 __device__ __attribute__((aligned(16))) float sbr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};

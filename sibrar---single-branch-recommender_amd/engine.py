@@ -113,7 +113,11 @@ class _EntityRun:
             bucket = 64
             while bucket * bucket < 4 * R:
                 bucket *= 2
-            counts = (counts + bucket - 1) // bucket * bucket
+            # bucket grid shifted so that the expected count R / n_modalities sits in the MIDDLE of a bucket (+- 2 sigma and
+            # more on either side): one signature then covers nearly every step. With the grid at multiples of the bucket a
+            # count whose mean is such a multiple (c2: 45056 = 44 * 1024) flips between two capacities from step to step.
+            off = (R // len(order) + bucket // 2) % bucket
+            counts = np.where(counts > 0, (np.maximum(counts - off, 0) + bucket - 1) // bucket * bucket + off, 0)
         return flat, pos.shape[1], tuple(int(c) for c in counts), tuple(order), R, bool(pad)
 
     def forward(self, idx: torch.Tensor, plan, seed: int, pos_dev: Optional[torch.Tensor] = None):

@@ -320,7 +320,7 @@ def test_fused_step_graph_replay_equals_plain_launches():
             continue
         # not bit-equal: split-K chunking follows the (padded) row counts and the table gradients use float atomics; AdamW at
         # lr 1e-2 turns that rounding noise into ~1e-6 absolute differences on near-zero gradients
-        close(runs[1][2][k].double(), runs[0][2][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
+        close(runs[1][2][k].double(), runs[0][2][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)
 
 
 @pytest.mark.gpu
@@ -354,4 +354,5 @@ def test_loader_pipeline_equals_inline_steps():
     skip = set(bn_shadowed_biases(finals[0][1].keys())) | {'item_embedding_module.sb_net.1.bias'}
     for k in finals[0][1]:
         if k not in skip:
-            close(finals[1][1][k].double(), finals[0][1][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
+            # AdamW (lr 1e-2, 12 steps) amplifies summation-order noise of small gradients: a few 1e-5 on single elements
+            close(finals[1][1][k].double(), finals[0][1][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)

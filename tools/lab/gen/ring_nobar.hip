@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : (NS == 2 ? 2 : 
     // slabs follow, so wait for everything
     if (q + NS - 1 <= q_total) ring_wait_vmcnt<(NS - 2) * PER_T>();
     else ring_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                              // every wave's part of slab q landed; slab q - 1 consumed
+
     asm volatile("" ::: "memory");
     if (issued < q_total) {
       issue(issued % NS);                                      // == (q - 1) % NS, the slot freed by the barrier
@@ -324,10 +324,10 @@ __global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : (NS == 2 ? 2 : 
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j][0] += fa[i].x * fb[j].x;
-          acc[i][j][0] += fa[i].y * fb[j].y;
-          acc[i][j][0] += fa[i].z * fb[j].z;
-          acc[i][j][0] += fa[i].w * fb[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
     if (++cp_slab == spt) {

@@ -93,7 +93,7 @@ __device__ __forceinline__ void ring_store(f32x16 (&acc)[MI][2], float* __restri
 }
 
 template <int MI, bool A_KM, bool B_KN, int NS>
-__global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : 1)) void gemm_ring_kernel(GemmArgs g, int n_items) {
+__global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : (NS == 2 ? 2 : 1))) void gemm_ring_kernel(GemmArgs g, int n_items) {
   constexpr int BM = 64 * MI, BN = 128;
   constexpr int A_BYTES = BM * RK * 4, B_BYTES = BN * RK * 4, STAGE = A_BYTES + B_BYTES;
   using SA = RingSrc<BM, A_KM>;
@@ -426,6 +426,17 @@ int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s) {
   // 64 x 128 tiles, 2-slot ring, three workgroups per CU. Measured alternatives (MI355X, us for 90112x128x128 NT /
   // 45056x128x768 gathered NT / 8192x50000x128 NT): 3 slots + 2 WG/CU 39.0 / 99.5 / 1146; 128 x 128 tiles, 4 slots, 1 WG/CU
   // 43.1 / 130.4 / 1175; this configuration 38.3 / 93.3 / 1091 — more waves per SIMD beat a deeper ring.
+  // 128 x 128 tiles (2 WG/CU) once there are enough of them to fill the 512 workgroup slots more than once: 90112x128x128
+  // 36.4 vs 38.6 us, 8192x50000x128 1022 vs 1118 us (103 TFLOP/s), 4096^3 124 vs 117 TFLOP/s; the 45056x128x768 projection has
+  // only 352 such tiles and stays on 64 x 128 (94 vs 112 us). TN stays on 64 x 128 (the split count provides the items).
+  const long big_items = (long)sbr_cdiv(g.M, 128) * sbr_cdiv(g.N, 128);
+  int big = mode != 2 && big_items >= 640;
+  if (getenv("SBR_RING_MI")) big = atoi(getenv("SBR_RING_MI")) == 2;       // tuning aid
+  if (big) {
+    if (mode == 0) return ring_launch<2, false, false, 2>(g, s);
+    if (mode == 1) return ring_launch<2, false, true, 2>(g, s);
+    return ring_launch<2, true, true, 2>(g, s);
+  }
   if (mode == 0) return ring_launch<1, false, false, 2>(g, s);
   if (mode == 1) return ring_launch<1, false, true, 2>(g, s);
   return ring_launch<1, true, true, 2>(g, s);

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : (NS == 2 ? 2 : 
           fa[i] = make_float4(v.x, v.y, v.z, v.w);
         } else {
           const lds_f32* p = As + ((a_rd[i] + kq * 8 * BM * 4) >> 2);
-          fa[i] = make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+          fa[i] = make_float4(1.f + kq, 2.f, 3.f + i, 4.f); (void)p;
         }
       }
 #pragma unroll
@@ -317,17 +317,17 @@ __global__ __launch_bounds__(256, (MI == 1 ? (NS == 2 ? 3 : 2) : (NS == 2 ? 2 : 
           fb[j] = make_float4(v.x, v.y, v.z, v.w);
         } else {
           const lds_f32* p = Bs + ((b_rd[j] + kq * 8 * BN * 4) >> 2);
-          fb[j] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+          fb[j] = make_float4(1.f + kq, 2.f, 3.f + j, 4.f); (void)p;
         }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j][0] += fa[i].x * fb[j].x;
-          acc[i][j][0] += fa[i].y * fb[j].y;
-          acc[i][j][0] += fa[i].z * fb[j].z;
-          acc[i][j][0] += fa[i].w * fb[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
     if (++cp_slab == spt) {
