@@ -329,6 +329,10 @@ class FusedTrainStep:
         self.n_replays = 0
         self._up_stream = None
         self._label_cache = {}
+        # two-phase launch (and two graphs) when gradients are exchanged: see _reduce_user_part. SBR_FORCE_SPLIT=1 exercises
+        # the same launch structure on one GPU.
+        self.split = parallel.is_distributed() or os.environ.get('SBR_FORCE_SPLIT', '0') == '1'
+        self._urange = self._user_range()
         _LIVE.add(self)
         self.opt.zero_grad()
 
@@ -342,6 +346,13 @@ class FusedTrainStep:
 
     # ---- the launches of forward + losses + backward (no host work besides ctypes calls) -------------------------------------
     def _fwd_bwd(self, u, i, lab, pu, pi, su, si, seed):
+        self._phase1(u, i, lab, pu, pi, su, si, seed)
+        return self._phase2()
+
+    def _phase1(self, u, i, lab, pu, pi, su, si, seed):
+        """Forward, losses, scorer backward and the USER side's backward: after this phase every user-side gradient is final,
+        so a data-parallel run can start reducing that part of the flat gradient buffer (for a lookup user side the whole
+        user embedding table) while phase 2 runs."""
         a, st = self.arena, ops.stream()
         B, N = i.shape
         a.reset()
@@ -364,8 +375,14 @@ class FusedTrainStep:
         call('sbr_rec_loss_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(self.one64), 1, ptr(dlog), st)
         dU, dI = a.f32(B, D), a.f32(B * N, D)
         call('sbr_score_dot_bwd', ptr(dlog), ptr(ur), ptr(ir), ptr(dU), ptr(dI), B, N, D, st)
-        self.item.backward(dI, self.one32)
         self.user.backward(dU, self.one32)
+        self._p2 = (dI, loss)
+
+    def _phase2(self):
+        """The item side's backward (the bulk of the step) and the loss scalars."""
+        a, st = self.arena, ops.stream()
+        dI, loss = self._p2
+        self.item.backward(dI, self.one32)
         out = a.f64(3)                                               # (total, rec, reg)
         ru, ri = self.user.reg_loss, self.item.reg_loss
         call('sbr_pack_losses', ptr(loss), ptr(ru), float(getattr(self.user, 'reg_w', 0.0)), ptr(ri),
@@ -473,10 +490,17 @@ class FusedTrainStep:
         cs.graph = torch.cuda.CUDAGraph()
         torch.cuda.current_stream().synchronize()
         # thread_local: the loader thread keeps issuing its own copies / kernels on its streams meanwhile
+        cs.graph2 = None
         with torch.cuda.graph(cs.graph, capture_error_mode='thread_local'):
             with pin_stream():
-                cs.out = self._fwd_bwd(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi,
-                                       cs.su, cs.si, 0)
+                self._phase1(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi, cs.su, cs.si, 0)
+                if not self.split:
+                    cs.out = self._phase2()
+        if self.split:                                               # second graph, same memory pool, replayed in order
+            cs.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cs.graph2, pool=cs.graph.pool(), capture_error_mode='thread_local'):
+                with pin_stream():
+                    cs.out = self._phase2()
         self._graphs[key] = cs
         return cs
 
@@ -518,17 +542,53 @@ class FusedTrainStep:
                             cs.su.copy_(pb.su, non_blocking=True)
                         cs.si.copy_(pb.si, non_blocking=True)
                     cs.graph.replay()
+                    pending = self._reduce_user_part()
+                    if cs.graph2 is not None:
+                        cs.graph2.replay()
                     self.n_replays += 1
                     out = cs.out.clone().unbind(0)
             if out is None:
-                out = self._fwd_bwd(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si,
-                                    seed).clone().unbind(0)
+                self._phase1(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si, seed)
+                pending = self._reduce_user_part()
+                out = self._phase2().clone().unbind(0)
             # ---- reduce + update
-            if parallel.is_distributed():
-                parallel.all_reduce_flat_(self.opt.fp.grad)
+            self._reduce_rest(pending)
             self.opt.step_flat()
             self.opt.fp.grad.zero_()
             return out
+
+    # ---- data-parallel gradient exchange, overlapped with the item side's backward -----------------------------------------------
+    def _user_range(self):
+        """[lo, hi) of the user side's parameters in the flat buffers, or None when they are not one contiguous run."""
+        fp = self.opt.fp
+        ids = {id(p) for p in self.net.user_embedding_module.parameters()}
+        idx = [k for k, p in enumerate(fp.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        hi = fp.offsets[idx[-1] + 1] if idx[-1] + 1 < len(fp.offsets) else fp.total
+        return fp.offsets[idx[0]], hi
+
+    def _reduce_user_part(self):
+        """After phase 1: start the all-reduce of the user side's gradients on RCCL's stream (asynchronous: the launches of
+        phase 2 go to the compute stream right behind). Returns the pending work handle (None when not distributed)."""
+        if not (self.split and parallel.is_distributed()) or self._urange is None:
+            return None
+        lo, hi = self._urange
+        return parallel.all_reduce_async(self.opt.fp.grad[lo:hi])
+
+    def _reduce_rest(self, pending):
+        if not parallel.is_distributed():
+            return
+        g = self.opt.fp.grad
+        if pending is None:
+            parallel.all_reduce_flat_(g)
+            return
+        lo, hi = self._urange
+        parts = [g[:lo], g[hi:]]
+        works = [parallel.all_reduce_async(t) for t in parts if t.numel()]
+        for w in works + [pending]:
+            w.wait()                                                  # the compute stream waits; the host does not block
+        g.div_(parallel.world_size())
 
     def close(self):
         """Drop the captured graphs (also done at interpreter exit: hipGraph objects must not outlive the HIP runtime)."""
@@ -550,4 +610,4 @@ def _drop_graphs():
 
 
 class _CapturedStep:
-    __slots__ = ('graph', 'packed', 'u', 'i', 'lab', 'su', 'si', 'out')
+    __slots__ = ('graph', 'graph2', 'packed', 'u', 'i', 'lab', 'su', 'si', 'out')

@@ -37,6 +37,18 @@ def all_reduce_flat_(grad: torch.Tensor) -> torch.Tensor:
     return grad
 
 
+def world_size() -> int:
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def all_reduce_async(t: torch.Tensor):
+    """Starts the SUM all-reduce of a contiguous slice of the flat gradient buffer; returns the work handle (``wait()`` makes
+    the current stream wait for it) or None when not distributed. The caller divides by the world size."""
+    if not is_distributed():
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def all_reduce_grads(optimizer) -> None:
     """Called by Trainer.train_step between backward and step. ``optimizer`` is an optim.FusedOptimizer."""
     if not is_distributed():

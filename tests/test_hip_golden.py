@@ -278,12 +278,15 @@ def test_fused_step_matches_autograd_path(user_kind, loss_name, B):
 
 
 @pytest.mark.gpu
-def test_fused_step_graph_replay_equals_plain_launches():
+@pytest.mark.parametrize('split', [False, True], ids=['one_graph', 'two_phase'])
+def test_fused_step_graph_replay_equals_plain_launches(split, monkeypatch):
     """hipGraph replay of forward+backward (engine.FusedTrainStep, use_graph=True) == the same launches issued one by one:
     same losses and parameters after 12 AdamW steps on a small c2-shaped world (text modality + item-id embedding, both
     one of them drawn per index, so the per-modality row counts vary from step to step and the plans are padded to a
-    bucket; a signature is captured at its second sighting)."""
+    bucket; a signature is captured at its second sighting). ``two_phase``: the launch structure of a data-parallel run (user
+    side backward first, two graphs, the gradient exchange of the user part would start in between) on one GPU."""
     import sibrar_amd as S
+    monkeypatch.setenv('SBR_FORCE_SPLIT', '1' if split else '0')
     ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
     cfg = {'shared_common_dim': 32, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
            'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
@@ -307,7 +310,7 @@ def test_fused_step_graph_replay_equals_plain_launches():
             labels[:, 0] = 1
             losses.append(torch.stack(fused.step(u, i, labels)).cpu())
         runs.append((fused, losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
-    assert runs[0][0].n_replays == 0
+    assert runs[0][0].n_replays == 0 and runs[1][0].split == split
     assert runs[1][0].n_replays >= 4                        # 64 x 4 = 256 draws, bucket 64: at most 2-3 signatures
     for s_, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
         close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
