@@ -52,6 +52,9 @@ struct RingSrc {
   int col;                                                   // k-major: first column of this thread's chunk (< 0: outside)
 };
 
+// (Tried: interleaved column tiles — tile j = columns 2*lane + j, one 8-byte store per row instead of two 4-byte stores 128
+// bytes apart. The B-fragment rows then sit 256 bytes apart in LDS, a two-way bank conflict that the 8-chunk swizzle cannot
+// remove: 90112x128x128 39.2 vs 36.4 us, 8192x50000x128 1108 vs 1022 us. Dropped.)
 // Stores the MI x 2 accumulator tiles of one wave. base: tile origin (uniform), ld: row stride, (row_l, col_l): this lane's
 // first row / column inside the tile, full: the tile lies inside the matrix (uniform) — otherwise rows >= m_left / columns >=
 // n_left are skipped; ci: optional row scatter (row r of the tile goes to row ci[r] of C, base then has no row offset).
