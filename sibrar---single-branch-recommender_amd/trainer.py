@@ -62,6 +62,15 @@ class Trainer:
                     self.fused = FusedTrainStep(model, rec_loss, self.optimizer)
             except NotImplementedError:
                 self.fused = None
+        # a NegativeSamplingDataLoader of this package without its own hooks gets the fused step's batch preparation (draw,
+        # plan, packed upload on the loader thread) and a prefetch depth; any other loader is consumed as it is
+        if self.fused is not None and train_loader is not None:
+            from .datasets import NegativeSamplingDataLoader
+            if isinstance(train_loader, NegativeSamplingDataLoader) and train_loader.prepare_fn is None \
+                    and train_loader.draw_fn is None:
+                train_loader.prepare_fn = self.fused.prepare
+                if train_loader.prefetch <= 0:
+                    train_loader.prefetch = 4
         logging.info(f'Built Trainer module - optimizer: {self.optimizer.name} lr: {self.lr} wd: {self.wd}')
 
     def fit(self):
