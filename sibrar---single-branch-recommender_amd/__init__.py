@@ -19,6 +19,7 @@ from .trainer import Trainer                                                    
 from .engine import FusedTrainStep                                                          # noqa: F401
 from .evaluation import FullEvaluator, evaluate_recommender_algorithm                       # noqa: F401
 from .datasets import NegativeSamplingDataLoader, SyntheticDataset                          # noqa: F401
+from .splitdata import SplitDataset, load_split_dataset                                     # noqa: F401
 from . import ops, parallel, sampling                                                       # noqa: F401
 
 # the reference's registry: AlgorithmsEnum.sbnet / .sgdbias -> class (algorithms/algorithms_utils.py:17,36)

@@ -399,3 +399,33 @@ def test_trainer_fit_end_to_end(tmp_path):
     fresh.load_model_from_path(str(tmp_path))
     sd_a, sd_b = fresh.state_dict(), None
     assert set(sd_a) == set(net.state_dict())
+
+
+@pytest.mark.gpu
+def test_split_dataset_trains_and_evaluates():
+    """The on-disk fixture (tests/golden/split_random, the reference's directory format) loaded with load_split_dataset drives the
+    whole path: SingleBranchNet over a tag + vector + id-embedding item entity and a categorical user feature, loader,
+    fused steps, full evaluation of the val split with the train interactions excluded."""
+    import os
+    import sibrar_amd as S
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'split_random')
+    fdefs = dict(user_feature_definitions=[{'name': 'gender', 'type': 'categorical'}],
+                 item_feature_definitions=[{'name': 'genres', 'type': 'tag', 'tag_split_sep': '|'}, {'name': 'text', 'type': 'vector'}])
+    train = S.load_split_dataset(here, 'train', n_negative_samples=3, **fdefs)
+    val = S.load_split_dataset(here, 'val', **fdefs)
+    cfg = {'shared_common_dim': 16, 'user': {'feature_name': 'gender', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'genres'}, {'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [16], 'preference_hidden_layers': [], 'common_modality_dim': 16}}
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), train).to(DEV)
+    loss = S.RecBayesianPersonalizedRankingLoss(n_items=train.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+    opt = S.FusedOptimizer(net, 'adamw', lr=1e-2, weight_decay=0.)
+    fused = S.FusedTrainStep(net, loss, opt)
+    net.train()
+    loader = S.NegativeSamplingDataLoader(train, batch_size=16, shuffle=True, device=DEV)
+    vals = [float(fused.step(*b)[0]) for _ in range(3) for b in loader]
+    assert len(vals) == 3 * len(loader) and all(np.isfinite(vals))
+    ev = S.FullEvaluator(config=S.evaluation._Cfg(top_k=(1, 5)), dataset=val)
+    res = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': val, 'batch_size': 8})(), ev, DEV)
+    assert 0.0 <= res['ndcg@5'] <= 1.0 and 'recall@1' in res

@@ -236,3 +236,55 @@ def test_native_legacy_randint_matches_numpy_stream(high, n):
     np.random.set_state(st)
     got, after2 = sampling.legacy_randint(high, n), np.random.randint(0, 1000, size=9)
     assert got.dtype == want.dtype and np.array_equal(got, want) and np.array_equal(after, after2)
+
+
+def _csr_eq(m, z, key):
+    import scipy.sparse as sp
+    m = sp.csr_matrix(m).astype(np.int64)
+    m.sum_duplicates()
+    m.sort_indices()
+    assert tuple(z[key + '/shape']) == m.shape, key
+    assert np.array_equal(m.indptr, z[key + '/indptr']) and np.array_equal(m.indices, z[key + '/indices']), key
+    assert np.array_equal(np.asarray(m.data).astype(np.int64), z[key + '/data']), key
+
+
+@pytest.mark.parametrize('name', ['split_random', 'split_cold_item'])
+@pytest.mark.parametrize('split', ['train', 'val', 'test'])
+def test_split_loader_matches_reference_datasets(name, split):
+    """sibrar_amd.load_split_dataset on the committed on-disk fixtures == what the reference's TrainRecDataset /
+    FullEvalDataset expose for the same directories (g12, generated with the real reference by make_golden_split.py)."""
+    import json
+    import sibrar_amd as S
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(here, 'g12_split_dataset.npz'), allow_pickle=False)
+    meta = json.load(open(os.path.join(here, 'g12_split_dataset.json')))[f'{name}/{split}']
+    ds = S.load_split_dataset(os.path.join(here, name), split,
+                              user_feature_definitions=[{'name': 'gender', 'type': 'categorical'}, {'name': 'age', 'type': 'discrete'}],
+                              item_feature_definitions=[{'name': 'genres', 'type': 'tag', 'tag_split_sep': '|'},
+                                                        {'name': 'text', 'type': 'vector'}], n_negative_samples=3)
+    p = f'{name}/{split}'
+    assert (ds.n_users, ds.n_items, ds.n_interactions) == (meta['n_users'], meta['n_items'], meta['n_interactions'])
+    assert (ds.is_cold_start_user, ds.is_cold_start_item) == (meta['is_cold_start_user'], meta['is_cold_start_item'])
+    assert np.array_equal(ds.users_in_split, z[p + '/users_in_split']) and np.array_equal(ds.items_in_split, z[p + '/items_in_split'])
+    for mname in ('interaction_matrix', 'user_sampling_matrix', 'user_sampling_matrix_train', 'item_sampling_matrix_train'):
+        _csr_eq(getattr(ds, mname), z, f'{p}/{mname}')
+    if split != 'train':
+        _csr_eq(ds.exclude_data, z, f'{p}/exclude_data')
+    for ent, feats in (('user', ds.user_features), ('item', ds.item_features)):
+        for fname, f in feats.items():
+            key, fm = f'{p}/{ent}/{fname}', meta['features'][f'{ent}/{fname}']
+            assert np.array_equal(np.asarray(f._indices), z[key + '/indices']), key
+            want = z[key + '/values']
+            if fm['type'] == 'tag':
+                # same tag ids per row; the order inside a row is the reference's set order there, sorted here
+                pad = len(fm['unique_values'])
+                assert f.dim == fm['dim'] == pad
+                got = np.asarray(f.values)
+                assert got.shape[0] == want.shape[0]
+                for a, b in zip(got, want):
+                    assert sorted(int(v) for v in a if v != pad) == sorted(int(v) for v in b if v != pad)
+            elif fm['type'] == 'categorical':
+                assert f.n_unique_categories == len(fm['unique_values']) and np.array_equal(np.asarray(f.values), want)
+            else:
+                got = np.asarray(f.values, dtype=np.float64).reshape(len(want), -1)
+                assert np.allclose(got, np.asarray(want, dtype=np.float64).reshape(len(want), -1))
