@@ -73,9 +73,11 @@ int sbr_partition_slots(const signed char* pos, long R, int n_mod, const int* se
  * rows_out[j] = rowmap_seg(j)[ idx[slots[j] / k] ] for the concatenated per-modality slot lists (segment s covers
  * [seg_offsets[s], seg_offsets[s+1])): the id -> row lookup of Feature.__getitem__ (data/Feature.py:146) on the
  * repeat_interleave'd index vector of algorithms/sgd_alg.py:1944-1946. rowmaps is a HOST array of n_seg device pointers
- * (NULL entry = identity). err_flag (device int) is set to 1 when an id is absent from a feature's split. */
+ * (NULL entry = identity), rowmap_lens a HOST array with the number of ids each map covers (identity: the number of rows).
+ * An id outside its map or mapped to -1 has no row in that feature's split: err_flag (device int, sticky) is set to 1 and
+ * row 0 is used instead, so that no consumer indexes out of bounds; the host turns the flag into the reference's KeyError. */
 int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg, const int* seg_offsets,
-                     const int* const* rowmaps, int* rows_out, int* err_flag, void* stream);
+                     const int* const* rowmaps, const int* rowmap_lens, int* rows_out, int* err_flag, void* stream);
 
 /* out[j] = 1 iff (rows[j], cols[j]) is a stored entry of the CSR matrix (sorted column indices): the `v in positives` test of
  * the negative-sampling collate, data/dataloader.py:184-191, for all slots of a round at once. */

@@ -77,12 +77,25 @@ def check(status: int):
 _FN = {}
 
 
+_TRACE = os.environ.get('SBR_TRACE_CALLS', '0') == '1'
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise SibrarHipError on a non-zero status."""
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(lib(), name)
-    if fn(*args) != 0:
+    if _TRACE:
+        # SBR_TRACE_CALLS=1 (debug aid): name every entry point before it runs and wait for it, so that a device fault is
+        # reported next to the launch that caused it
+        import sys
+        import torch
+        print(f'[sbr] {name} {args}', file=sys.stderr, flush=True)
+        rc = fn(*args)
+        torch.cuda.synchronize()
+    else:
+        rc = fn(*args)
+    if rc != 0:
         raise SibrarHipError(lib().sbr_last_error().decode())
 
 
@@ -114,3 +127,13 @@ class pin_stream:
     def __exit__(self, *exc):
         _STREAM[0] = self.prev
         return False
+
+
+def to_device(t, device):
+    """Host -> device copy that is asynchronous only for PINNED sources. An "async" copy from pageable memory may read the
+    host buffer after the call returned (observed on ROCm: a temporary staging tensor was recycled before its copy ran — garbage
+    indices on the device, then an out-of-bounds access in the kernels that consumed them), so pageable sources are copied
+    synchronously."""
+    if t.device.type != 'cpu':
+        return t.to(device, non_blocking=True)
+    return t.to(device, non_blocking=t.is_pinned())

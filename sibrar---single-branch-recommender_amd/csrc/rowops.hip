@@ -11,6 +11,7 @@ struct SegTable {
   int n_seg;
   int offs[SBR_MAX_SEG + 1];
   const int* maps[SBR_MAX_SEG];
+  int lens[SBR_MAX_SEG];            // ids covered by maps[s] (identity map: number of rows)
 };
 
 // rows[j] = map_seg(j)[ idx[slots[j] / k] ]  — Feature.__getitem__'s id -> row map (data/Feature.py:146) applied to the
@@ -22,21 +23,25 @@ __global__ void resolve_rows_kernel(const long* __restrict__ idx, int k, const i
   int seg = 0;
   while (seg + 1 < st.n_seg && j >= st.offs[seg + 1]) ++seg;
   const long id = idx[slots[j] / k];
-  int r = (int)id;
-  if (st.maps[seg]) r = st.maps[seg][id];
-  if (r < 0) atomicExch(err, 1);       // id not present in this feature's split
+  int r = -1;
+  if (id >= 0 && id < st.lens[seg]) r = st.maps[seg] ? st.maps[seg][id] : (int)id;
+  if (r < 0) {                          // id not present in this feature's split: flag it (the host raises KeyError at its next
+    atomicExch(err, 1);                 // check) and fall back to row 0 so that no kernel ever indexes out of bounds
+    r = 0;
+  }
   rows[j] = r;
 }
 
 extern "C" int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg, const int* seg_offsets,
-                                const int* const* rowmaps, int* rows_out, int* err_flag, void* stream) {
+                                const int* const* rowmaps, const int* rowmap_lens, int* rows_out, int* err_flag, void* stream) {
   SBR_REQUIRE(n_seg >= 1 && n_seg <= SBR_MAX_SEG, "sbr_resolve_rows: n_seg %d out of range", n_seg);
   SBR_REQUIRE(k >= 1, "sbr_resolve_rows: k must be >= 1");
   if (n == 0) return SBR_OK;
   SegTable st;
   st.n_seg = n_seg;
   for (int i = 0; i <= n_seg; ++i) st.offs[i] = seg_offsets[i];
-  for (int i = 0; i < n_seg; ++i) st.maps[i] = rowmaps[i];
+  SBR_REQUIRE(rowmaps && rowmap_lens && err_flag, "sbr_resolve_rows: null operand");
+  for (int i = 0; i < n_seg; ++i) { st.maps[i] = rowmaps[i]; st.lens[i] = rowmap_lens[i]; }
   resolve_rows_kernel<<<sbr_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(idx, k, slots, n, st, rows_out, err_flag);
   SBR_CHECK_LAUNCH("sbr_resolve_rows");
   return SBR_OK;

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from ._lib import call, pin_stream, ptr
+from ._lib import call, pin_stream, ptr, to_device
 from .config import EmbeddingRegularizationType
 from .losses import RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy, RecSampledSoftmaxLoss
 from .sbnet import FeatureEmbedding, SingleBranchNet, SingleBranchNetEntity, resolve_rows
@@ -127,7 +127,7 @@ class _EntityRun:
         self.padded = padded
         dev = idx.device
         if pos_dev is None:
-            pos_dev = torch.from_numpy(pos_flat).to(dev, non_blocking=True)
+            pos_dev = to_device(torch.from_numpy(pos_flat), dev)
         seg = [0]
         for c in counts:
             seg.append(seg[-1] + c)
@@ -144,7 +144,7 @@ class _EntityRun:
                 tables.append(fe._table)
                 offs.append(offs[-1] + c)
         idx_flat = idx.reshape(-1)
-        rows, _ = resolve_rows(idx_flat, k, slots, offs, tables)
+        rows, _ = resolve_rows(idx_flat, k, slots, offs, tables, ent._idx_err)
         self.entries, self.rows, self.slots, self.R, self.k, self.shape = entries, rows, slots, R, k, tuple(idx.shape)
         x0 = a.f32(R + 1 if padded else R, self.C)      # row R: landing row of the padded launches
         self.hidden = [fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n]) for fe, o, n in entries]
@@ -289,7 +289,7 @@ class _PlainRun:
         n = flat.numel()
         self.n = n
         self.slots = torch.arange(n, device=flat.device, dtype=torch.int32)
-        self.rows, _ = resolve_rows(flat, 1, self.slots, [0, n], [fe._table])
+        self.rows, _ = resolve_rows(flat, 1, self.slots, [0, n], [fe._table], fe._idx_err)
         self.out = a.f32(n, fe.front_dim)
         self.hidden = fe.front_forward(fe.front_params(), self.rows, n, self.out, None)
         return self.out
@@ -431,7 +431,7 @@ class FusedTrainStep:
                 hv = host.numpy()
                 for a_, o in zip(arrs, offs):
                     hv[o:o + a_.nbytes] = np.ascontiguousarray(a_).view(np.uint8).reshape(-1)
-                packed = host[:offs[-1]].to(dev, non_blocking=True)
+                packed = to_device(host[:offs[-1]], dev)             # pinned ring slot: asynchronous; pageable: synchronous
                 if ev is not None:
                     ev.record(stream)                                # the staging slot is free again after this copy
                 pb.packed, pb.layout = packed, tuple((o, a_.nbytes) for a_, o in zip(arrs, offs))
@@ -443,11 +443,11 @@ class FusedTrainStep:
                     self._label_cache[(labels_key, tuple(lab.shape))] = keep
             else:                                                     # indices already on the device
                 def ext(t):
-                    t = t.to(dev, non_blocking=True)
+                    t = to_device(t, dev)
                     return torch.cat([t, t[:1]])
-                pb.u, pb.i, pb.lab = ext(parts[0]), ext(parts[1]), parts[2].to(dev, non_blocking=True).contiguous()
-                pb.su = torch.from_numpy(pb.pu[0]).to(dev, non_blocking=True) if pb.pu is not None else None
-                pb.si = torch.from_numpy(pb.pi[0]).to(dev, non_blocking=True)
+                pb.u, pb.i, pb.lab = ext(parts[0]), ext(parts[1]), to_device(parts[2], dev).contiguous()
+                pb.su = to_device(torch.from_numpy(pb.pu[0]), dev) if pb.pu is not None else None
+                pb.si = to_device(torch.from_numpy(pb.pi[0]), dev)
             pb.event = None
             if ahead:
                 pb.event = torch.cuda.Event()
@@ -589,6 +589,10 @@ class FusedTrainStep:
         for w in works + [pending]:
             w.wait()                                                  # the compute stream waits; the host does not block
         g.div_(parallel.world_size())
+
+    def check_errors(self):
+        """Host check of the sticky missing-id flags (one device sync): raises KeyError like the reference's feature lookup."""
+        self.net.check_index_errors()
 
     def close(self):
         """Drop the captured graphs (also done at interpreter exit: hipGraph objects must not outlive the HIP runtime)."""

@@ -121,8 +121,14 @@ class FullEvaluator:
 
 
 def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, device='cuda', return_raw=False, verbose=False,
-                                   scorer: str = 'fp32'):
-    """eval/eval.py:171-227 (SGD branch :203-222). ``eval_loader`` only has to expose ``dataset`` and ``batch_size``."""
+                                   scorer: str = 'fp32', user_chunk: Optional[int] = None):
+    """eval/eval.py:171-227 (SGD branch :203-222). ``eval_loader`` only has to expose ``dataset`` and ``batch_size``.
+
+    The users are scored in engine-sized chunks, not in the loader's batches: per-user results do not depend on the grouping,
+    and the reference's default evaluation batch (256 users) leaves the GPU idle — the fused kernel assigns 224 users to a
+    workgroup and every workgroup streams the whole catalogue, so it wants >= 57k users per launch (measured on c2, 100k users:
+    975 ms with 256-user batches, 37 ms with 8192, 12 ms in one launch); the fp32 path is bounded by the [chunk, items] score
+    matrix it materialises. ``user_chunk`` overrides the choice."""
     dataset = eval_loader.dataset
     for attr in ('items_in_split', 'users_in_split', 'exclude_data'):
         if not hasattr(dataset, attr):
@@ -151,6 +157,12 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
             logging.info(f'fp16_fused scorer: k={kmax}, D={i_repr.shape[1]} outside the fused kernel, using the fp32 path')
             scorer = 'fp32'
         i16 = ops.cast_f16(i_repr) if scorer == 'fp16_fused' else None
+        if user_chunk is not None:
+            bs = int(user_chunk)
+        elif scorer == 'fp16_fused':
+            bs = max(bs, 262144)                                    # one launch for up to 256k users (fp16 rows: 64 MB at D = 128)
+        else:
+            bs = max(bs, min(16384, max(1, (1 << 31) // max(int(i_repr.shape[0]), 1))))      # <= 8 GiB of fp32 scores per chunk
         for s in range(0, len(users), bs):
             u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
             u_repr = alg.get_user_representations(u_idxs)
@@ -161,4 +173,6 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
                 ops.mask_scores_(out, u_idxs, excl[0], excl[1])
                 _, idx = ops.topk_rows(out, kmax)
             evaluator.eval_topk(u_idxs, idx)
+        if hasattr(alg, 'check_index_errors'):
+            alg.check_index_errors()
     return evaluator.get_results(return_raw_results=return_raw)

@@ -109,8 +109,9 @@ class DevicePositiveIndex:
         if n == 0:
             return np.zeros(0, dtype=bool)
         with torch.cuda.stream(self.stream):
-            u = torch.from_numpy(np.ascontiguousarray(users, dtype=np.int64)).to(self.device, non_blocking=True)
-            i = torch.from_numpy(np.ascontiguousarray(items, dtype=np.int64)).to(self.device, non_blocking=True)
+            # pageable sources: synchronous copies (see _lib.to_device)
+            u = torch.from_numpy(np.ascontiguousarray(users, dtype=np.int64)).to(self.device)
+            i = torch.from_numpy(np.ascontiguousarray(items, dtype=np.int64)).to(self.device)
             out = torch.empty(n, dtype=torch.uint8, device=self.device)
             call('sbr_csr_contains', ptr(self.indptr), ptr(self.indices), ptr(u), ptr(i), n, ptr(out), self.stream.cuda_stream)
             res = out.cpu()

@@ -76,6 +76,17 @@ class SGDBasedRecommenderAlgorithm(nn.Module):
     def get_and_reset_other_loss(self) -> Dict:
         return {'reg_loss': torch.zeros(1)}
 
+    def check_index_errors(self):
+        """Raises KeyError when any lookup since the last check met a user / item id that has no row in one of its features
+        (the reference raises it inside Feature.__getitem__, data/Feature.py:146; here the kernels flag it, substitute row 0
+        and keep going, and the host asks at its next synchronisation point: end of an epoch, end of an evaluation)."""
+        bad = [name for name, buf in self.named_buffers() if name.endswith('_idx_err') and int(buf.item()) != 0]
+        for name, buf in self.named_buffers():
+            if name.endswith('_idx_err'):
+                buf.zero_()
+        if bad:
+            raise KeyError('index without feature row in: ' + ', '.join(n.rsplit('.', 1)[0] or '<model>' for n in bad))
+
     @torch.no_grad()
     def predict(self, u_idxs: torch.Tensor, i_idxs: torch.Tensor) -> torch.Tensor:
         self.eval()
@@ -107,16 +118,21 @@ class _FrontPlan:
         self.entries, self.rows, self.slots, self.R, self.C = entries, rows, slots, R, C
 
 
-def resolve_rows(idx_flat: torch.Tensor, k: int, slots: torch.Tensor, seg_offsets: List[int], tables: List[DeviceTable]):
-    """One launch: slot -> entity id -> feature-table row (or category id) for all modalities of a plan."""
+def resolve_rows(idx_flat: torch.Tensor, k: int, slots: torch.Tensor, seg_offsets: List[int], tables: List[DeviceTable],
+                 err: Optional[torch.Tensor] = None):
+    """One launch: slot -> entity id -> feature-table row (or category id) for all modalities of a plan. ``err`` (device
+    int32[1], sticky) is set when an id has no row in a feature's split — the kernel then uses row 0, the host raises KeyError
+    (the reference's Feature.__getitem__ dict lookup, data/Feature.py:146) at its next ``check_index_errors``."""
     import ctypes
     n = int(seg_offsets[-1])
     rows = torch.empty(n, device=idx_flat.device, dtype=torch.int32)
-    err = torch.zeros(1, device=idx_flat.device, dtype=torch.int32)
+    if err is None:
+        err = torch.zeros(1, device=idx_flat.device, dtype=torch.int32)
     offs = (ctypes.c_int * len(seg_offsets))(*seg_offsets)
     maps = (ctypes.c_void_p * len(tables))(*[ptr(t.rowmap) for t in tables])
+    lens = (ctypes.c_int * len(tables))(*[int(t.rowmap.numel()) if t.rowmap is not None else int(t.n_rows) for t in tables])
     call('sbr_resolve_rows', ptr(idx_flat), k, ptr(slots), n, len(tables), ctypes.cast(offs, ctypes.c_void_p),
-         ctypes.cast(maps, ctypes.c_void_p), ptr(rows), ptr(err), stream())
+         ctypes.cast(maps, ctypes.c_void_p), ctypes.cast(lens, ctypes.c_void_p), ptr(rows), ptr(err), stream())
     return rows, err
 
 
@@ -174,6 +190,7 @@ class FeatureEmbedding(nn.Module):
                  post_embedding_layers: List[int] = None, activation_fn='relu'):
         super().__init__()
         self._table = DeviceTable(feature)
+        self.register_buffer('_idx_err', torch.zeros(1, dtype=torch.int32), persistent=False)   # sticky missing-id flag
         self.kind = self._table.kind
         name = getattr(feature.feature_definition, 'name', '?')
         self._embedding_dim = embedding_dim
@@ -327,7 +344,7 @@ class FeatureEmbedding(nn.Module):
         flat = indices.reshape(-1).long().contiguous()
         n = flat.numel()
         slots = torch.arange(n, device=flat.device, dtype=torch.int32)
-        rows, err = resolve_rows(flat, 1, slots, [0, n], [self._table])
+        rows, err = resolve_rows(flat, 1, slots, [0, n], [self._table], self._idx_err)
         plan = _FrontPlan([(self, 0, n)], rows, None, n, self.front_dim)
         x = FrontEndFn.apply(plan, *self.front_params())
         if self.post_embedding_layers is not None:
@@ -359,6 +376,7 @@ class SingleBranchNetEntity(nn.Module):
         self.entity_config = entity_config
         self.output_dim = shared_common_dim
         self.val_interactions_available = val_interactions_available
+        self.register_buffer('_idx_err', torch.zeros(1, dtype=torch.int32), persistent=False)      # sticky missing-id flag
 
         if len(entity_config.features) == 0:
             raise ValueError('SingleBranchEntity requires at least one feature.')
@@ -459,7 +477,8 @@ class SingleBranchNetEntity(nn.Module):
         order_idx = np.argsort(flat_mods, kind='stable').astype(np.int32)
         counts = np.bincount(flat_mods, minlength=len(order))
         dev = indices.device
-        slots = torch.from_numpy(order_idx).to(dev, non_blocking=True)
+        from ._lib import to_device
+        slots = to_device(torch.from_numpy(order_idx), dev)
         entries, tables, offs = [], [], [0]
         for m, c in enumerate(counts.tolist()):
             if c == 0:
@@ -469,8 +488,7 @@ class SingleBranchNetEntity(nn.Module):
             tables.append(fe._table)
             offs.append(offs[-1] + c)
         idx_flat = indices.reshape(-1).long().contiguous()
-        rows, err = resolve_rows(idx_flat, k, slots, offs, tables)
-        self._last_err = err
+        rows, err = resolve_rows(idx_flat, k, slots, offs, tables, self._idx_err)
         plan = _FrontPlan(entries, rows, slots, R, self.entity_config.common_modality_dim)
         params = [p for fe, _, _ in entries for p in fe.front_params()]
         return FrontEndFn.apply(plan, *params)

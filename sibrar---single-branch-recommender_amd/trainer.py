@@ -115,9 +115,8 @@ class Trainer:
         if self.fused is not None:
             total, rec, reg = self.fused.step(u_idxs, i_idxs, labels, draws)
             return total, rec, {'reg_loss': reg}
-        u_idxs = u_idxs.to(self.device, non_blocking=True)
-        i_idxs = i_idxs.to(self.device, non_blocking=True)
-        labels = labels.to(self.device, non_blocking=True)
+        from ._lib import to_device
+        u_idxs, i_idxs, labels = (to_device(t, self.device) for t in (u_idxs, i_idxs, labels))
         out = self.model(u_idxs, i_idxs)
         rec_loss = self.rec_loss.compute_loss(out, labels)
         reg_losses = self.pointer_to_model.get_and_reset_other_loss()
@@ -143,6 +142,8 @@ class Trainer:
             if self.max_batches is not None and self.max_batches <= batch_count + 1:
                 print(f'limit of {self.max_batches} batches hit, thus stopping this training cycle.')
                 break
+        if hasattr(self.pointer_to_model, 'check_index_errors'):
+            self.pointer_to_model.check_index_errors()                               # ids without a feature row -> KeyError
         return {f'train/{k}': float(v) / n_batches for k, v in sums.items()}        # one host sync per epoch
 
     @torch.no_grad()

@@ -55,14 +55,15 @@ def write_dir(name, cold_item):
         lh.to_csv(os.path.join(d, f'listening_history_{s}.csv'), index=False)
     genders = np.array(['F', 'M', 'F', 'M', 'M', 'F', 'M', 'F', 'X', 'M', 'F', 'M'])     # 'X' appears only outside train
     ages = rng.integers(18, 60, size=U)
-    user_rows = {'train': np.arange(0, 8), 'val': np.arange(6, 10), 'test': np.arange(0, U)}
+    # train + val together cover every user / item (a training run looks features up in their union, dataset.py:213-214)
+    user_rows = {'train': np.arange(0, 8), 'val': np.arange(6, U), 'test': np.arange(0, U)}
     for s, rows in user_rows.items():
         pd.DataFrame({'user': [f'u{k}' for k in rows], 'user_idx': rows, 'gender': genders[rows], 'age': ages[rows],
                       'unused': 1}).to_csv(os.path.join(d, f'user_features_{s}.csv'), index=False)
     tags = ['rock|pop', 'jazz', 'pop', 'rock|metal|pop', 'folk', 'jazz|folk', 'metal', 'classical', 'pop|classical|jazz|rock']
     text = rng.standard_normal((I, 5)).astype(np.float32)
     for s in ('train', 'val', 'test'):
-        rows = item_sets[s] if cold_item else {'train': np.arange(0, 7), 'val': np.array([8, 5, 6]), 'test': np.arange(I)}[s]
+        rows = item_sets[s] if cold_item else {'train': np.arange(0, 7), 'val': np.array([8, 5, 6, 7]), 'test': np.arange(I)}[s]
         pd.DataFrame({'item': [f'i{k}' for k in rows], 'item_idx': rows, 'genres': [tags[k] for k in rows]}) \
             .to_csv(os.path.join(d, f'item_features_{s}.csv'), index=False)
         np.savez(os.path.join(d, f'item_text_{s}.npz'), indices=np.asarray(rows), values=text[rows])

@@ -429,3 +429,44 @@ def test_split_dataset_trains_and_evaluates():
     ev = S.FullEvaluator(config=S.evaluation._Cfg(top_k=(1, 5)), dataset=val)
     res = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': val, 'batch_size': 8})(), ev, DEV)
     assert 0.0 <= res['ndcg@5'] <= 1.0 and 'recall@1' in res
+
+
+@pytest.mark.gpu
+def test_missing_feature_row_raises_keyerror_not_a_fault():
+    """An item id without a row in one of its features (the reference: KeyError from Feature.__getitem__'s dict lookup,
+    data/Feature.py:146). The kernels must stay in bounds (row 0 is substituted) and the host must raise KeyError at its next
+    check — also for ids beyond the end of the id -> row map."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(50, 30, 400, item_dense={'text': 8}, seed=2, n_negative_samples=3)
+    f = ds.item_features['text']
+    keep = np.arange(0, 20)                                   # items 20..29 have no 'text' row
+    ds.item_features['text'] = S.features.HostFeature('text', 'dense', np.asarray(f.values)[keep], indices=keep)
+    cfg = {'shared_common_dim': 8, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [8], 'preference_hidden_layers': [], 'common_modality_dim': 8}}
+    torch.manual_seed(0)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+    net.train()
+    loss = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+    fused = S.FusedTrainStep(net, loss, S.FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=0.))
+    u = torch.arange(16)
+    ok_items = torch.from_numpy(np.random.default_rng(0).integers(0, 20, size=(16, 4)))
+    labels = torch.zeros(16, 4, dtype=torch.float64)
+    for _ in range(3):
+        fused.step(u, ok_items, labels)
+    fused.check_errors()                                      # all ids covered: nothing raised
+    bad_items = ok_items.clone()
+    bad_items[3, 2] = 27                                      # beyond the text map (length 20)
+    for _ in range(3):                                        # enough steps for 'text' to be drawn for that slot
+        fused.step(u, bad_items, labels)
+    out = fused.step(u, bad_items, labels)
+    assert torch.isfinite(torch.stack(list(out))).all()
+    with pytest.raises(KeyError):
+        for _ in range(20):
+            fused.step(u, bad_items, labels)
+        fused.check_errors()
+    fused.check_errors()                                      # the flag was reset by the raising check
+    net.eval()
+    with pytest.raises(KeyError):
+        net.get_item_representations(torch.arange(30, device=DEV))
+        net.check_index_errors()
