@@ -121,6 +121,10 @@ int sbr_l2norm_bwd(const float* dY, const float* Y, const float* inv_norm, float
 /* nn.Dropout(p) — algorithms/sgd_alg.py:1815, modules/polylinear.py:48; counter-based mask from (seed, element index),
  * the same call maps dY -> dX in the backward pass. */
 int sbr_dropout(const float* X, float* Y, long total, float p, unsigned long long seed, void* stream);
+/* the same with the seed in device memory (seed = seed_dev[0] + seed_offset, read when the kernel runs): a captured hipGraph
+ * replays the launch while the host refreshes seed_dev[0] per step. sbr_dropout(seed) == sbr_dropout_dev with
+ * seed_dev[0] + seed_offset == seed. */
+int sbr_dropout_dev(const float* X, float* Y, long total, float p, const long* seed_dev, long seed_offset, void* stream);
 
 /* aggregation over the k sampled modalities — algorithms/sgd_alg.py:27-31, 1861. mode 0 mean, 1 max. */
 int sbr_aggregate_fwd(const float* E, float* out, unsigned char* argmax, long S, int k, int D, int mode, void* stream);

@@ -595,7 +595,8 @@ __device__ __forceinline__ unsigned int sbr_mix(unsigned long long z) {
 }
 
 __global__ void dropout_kernel(const float* __restrict__ X, float* __restrict__ Y, long total, float p,
-                               unsigned long long seed) {
+                               unsigned long long seed, const long* __restrict__ seed_dev) {
+  if (seed_dev) seed += (unsigned long long)seed_dev[0];     // step seed kept in device memory (hipGraph replay)
   const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
   const float scale = 1.f / (1.f - p);
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
@@ -609,8 +610,22 @@ extern "C" int sbr_dropout(const float* X, float* Y, long total, float p, unsign
   SBR_REQUIRE(p >= 0.f && p < 1.f, "sbr_dropout: p must be in [0, 1)");
   int blocks = sbr_cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;
-  dropout_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, Y, total, p, seed);
+  dropout_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, Y, total, p, seed, nullptr);
   SBR_CHECK_LAUNCH("sbr_dropout");
+  return SBR_OK;
+}
+
+// the same map with the step's seed read from device memory at run time: mask = f(seed_dev[0] + seed_offset, element). A
+// captured hipGraph replays this launch unchanged while the host refreshes seed_dev[0] before every replay.
+extern "C" int sbr_dropout_dev(const float* X, float* Y, long total, float p, const long* seed_dev, long seed_offset,
+                               void* stream) {
+  if (total == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y && seed_dev, "sbr_dropout_dev: null operand");
+  SBR_REQUIRE(p >= 0.f && p < 1.f, "sbr_dropout_dev: p must be in [0, 1)");
+  int blocks = sbr_cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  dropout_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, Y, total, p, (unsigned long long)seed_offset, seed_dev);
+  SBR_CHECK_LAUNCH("sbr_dropout_dev");
   return SBR_OK;
 }
 

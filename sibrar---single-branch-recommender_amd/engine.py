@@ -157,7 +157,8 @@ class _EntityRun:
         self.seed = None
         if self.p_drop:
             xd = a.f32(R, self.C)
-            call('sbr_dropout', ptr(x), ptr(xd), x.numel(), float(self.p_drop), seed, st)
+            # seed = (step seed in device memory, part of the batch upload) + a per-side offset: replayable in a hipGraph
+            call('sbr_dropout_dev', ptr(x), ptr(xd), x.numel(), float(self.p_drop), ptr(seed[0]), int(seed[1]), st)
             self.seed, x = seed, xd
         self.acts = []                                   # per layer: (input, pre-BN output | None, output, mean, rstd)
         for lin, bn, act in self.layers:
@@ -257,7 +258,7 @@ class _EntityRun:
         if self.seed is not None:
             tail -= 1
             dd = dx0[:R] if not tail else a.f32(R, self.C)
-            call('sbr_dropout', ptr(d), ptr(dd), d.numel(), float(self.p_drop), self.seed, st)
+            call('sbr_dropout_dev', ptr(d), ptr(dd), d.numel(), float(self.p_drop), ptr(self.seed[0]), int(self.seed[1]), st)
             d = dd
         if self.normalize:
             dn = dx0[:R]
@@ -302,9 +303,9 @@ class _PlainRun:
 
 class FusedTrainStep:
     """``use_graph`` (default: on, env ``SBR_GRAPH=0`` turns it off): forward + backward of a step are captured once per
-    batch signature into a hipGraph and replayed — one launch instead of ~45 — whenever the step is a pure function of
-    device buffers: no dropout (its seed is a kernel argument) and a modality draw whose per-modality row counts repeat
-    (k == number of modalities; random modality dropout changes the launch sizes every step and stays on plain launches).
+    batch signature into a hipGraph and replayed — one launch instead of ~50. The step is made a pure function of device
+    buffers: the modality plans are padded to bucketed capacities (``_EntityRun.plan``), the dropout seed of the step travels
+    in the batch upload and is read from device memory by the dropout kernels (``sbr_dropout_dev``).
     The gradient all-reduce and the optimizer launch stay outside the graph (RCCL call, step-dependent scalars)."""
 
     MAX_GRAPHS = 16
@@ -323,7 +324,8 @@ class FusedTrainStep:
         self.n_steps = 0
         if use_graph is None:
             use_graph = os.environ.get('SBR_GRAPH', '1') != '0'
-        self.use_graph = bool(use_graph) and not any(getattr(side, 'p_drop', 0) for side in (self.user, self.item))
+        self.use_graph = bool(use_graph)
+        self._n_prepared = 0
         self._graphs = {}            # batch signature -> None (seen once, run eagerly) | _CapturedStep
         self._arena_buf = None
         self.n_replays = 0
@@ -356,8 +358,8 @@ class FusedTrainStep:
         a, st = self.arena, ops.stream()
         B, N = i.shape
         a.reset()
-        ur = self.user.forward(u, pu, seed, su)                      # [B, D]
-        ir = self.item.forward(i, pi, seed + 1, si)                  # [B*N, D]
+        ur = self.user.forward(u, pu, (seed, 0), su)                 # [B, D]; seed: device int64[1] of this step
+        ir = self.item.forward(i, pi, (seed, 1), si)                 # [B*N, D]
         D = ir.shape[-1]
         logits = a.f32(B, N)
         call('sbr_score_dot_fwd', ptr(ur), ptr(ir), ptr(logits), B, N, D, st)
@@ -407,6 +409,8 @@ class FusedTrainStep:
         pb.u_shape, pb.i_shape = tuple(u.shape), tuple(i.shape)
         pb.pu, pb.pi = self.user.plan(du, pad), self.item.plan(di, pad)
         pb.packed = pb.layout = None
+        self._n_prepared += 1                                        # dropout seed of this step (travels with the batch)
+        seed = (torch.initial_seed() * 1000003 + 2 * self._n_prepared) & 0x3FFFFFFFFFFFFFFF
         pb.lab_cached = False
         cached_lab = self._label_cache.get((labels_key, tuple(lab.shape))) if labels_key is not None else None
         if ahead and self._up_stream is None:
@@ -415,12 +419,12 @@ class FusedTrainStep:
         parts = [u.reshape(-1), i.reshape(-1), lab.reshape(-1)]
         with torch.cuda.device(dev), torch.cuda.stream(stream):
             if all(t.device.type == 'cpu' for t in parts):
-                # one packed H2D copy: [u | u[0] | i | i[0] | labels | user modality draw | item modality draw], 16-byte
-                # aligned segments
+                # one packed H2D copy: [u | u[0] | i | i[0] | labels | user modality draw | item modality draw | dropout seed],
+                # 16-byte aligned segments
                 un, inn = parts[0].numpy(), parts[1].numpy()
                 arrs = [np.concatenate([un, un[:1]]), np.concatenate([inn, inn[:1]]),
                         parts[2].numpy() if cached_lab is None else np.empty(0, np.float64),
-                        pb.pu[0] if pb.pu is not None else np.empty(0, np.int8), pb.pi[0]]
+                        pb.pu[0] if pb.pu is not None else np.empty(0, np.int8), pb.pi[0], np.array([seed], dtype=np.int64)]
                 offs = [0]
                 for a_ in arrs:
                     offs.append((offs[-1] + a_.nbytes + 15) & ~15)
@@ -435,7 +439,7 @@ class FusedTrainStep:
                 if ev is not None:
                     ev.record(stream)                                # the staging slot is free again after this copy
                 pb.packed, pb.layout = packed, tuple((o, a_.nbytes) for a_, o in zip(arrs, offs))
-                pb.u, pb.i, pb.lab, pb.su, pb.si = self._views(packed, pb.layout, pb.pu is not None)
+                pb.u, pb.i, pb.lab, pb.su, pb.si, pb.seed = self._views(packed, pb.layout, pb.pu is not None)
                 if cached_lab is not None:
                     pb.lab, pb.lab_cached = cached_lab, True
                 elif labels_key is not None:
@@ -448,6 +452,7 @@ class FusedTrainStep:
                 pb.u, pb.i, pb.lab = ext(parts[0]), ext(parts[1]), to_device(parts[2], dev).contiguous()
                 pb.su = to_device(torch.from_numpy(pb.pu[0]), dev) if pb.pu is not None else None
                 pb.si = to_device(torch.from_numpy(pb.pi[0]), dev)
+                pb.seed = torch.tensor([seed], dtype=torch.int64, device=dev)
             pb.event = None
             if ahead:
                 pb.event = torch.cuda.Event()
@@ -457,7 +462,7 @@ class FusedTrainStep:
     @staticmethod
     def _views(packed, layout, has_su):
         v = [packed[o:o + n].view(dt) for (o, n), dt in
-             zip(layout, (torch.int64, torch.int64, torch.float64, torch.int8, torch.int8))]
+             zip(layout, (torch.int64, torch.int64, torch.float64, torch.int8, torch.int8, torch.int64))]
         if not has_su:
             v[3] = None
         return v
@@ -479,7 +484,7 @@ class FusedTrainStep:
         cs = _CapturedStep()
         if pb.packed is not None:                                    # static copy of the packed upload: one D2D per replay
             cs.packed = torch.empty_like(pb.packed)
-            cs.u, cs.i, cs.lab, cs.su, cs.si = self._views(cs.packed, pb.layout, pb.su is not None)
+            cs.u, cs.i, cs.lab, cs.su, cs.si, cs.seed = self._views(cs.packed, pb.layout, pb.su is not None)
             if pb.lab_cached:
                 cs.lab = pb.lab                                      # device-resident constant labels: nothing to copy
         else:
@@ -487,13 +492,14 @@ class FusedTrainStep:
             cs.u, cs.i, cs.lab = torch.empty_like(pb.u), torch.empty_like(pb.i), torch.empty_like(pb.lab)
             cs.su = torch.empty_like(pb.su) if pb.su is not None else None
             cs.si = torch.empty_like(pb.si)
+            cs.seed = torch.empty_like(pb.seed)
         cs.graph = torch.cuda.CUDAGraph()
         torch.cuda.current_stream().synchronize()
         # thread_local: the loader thread keeps issuing its own copies / kernels on its streams meanwhile
         cs.graph2 = None
         with torch.cuda.graph(cs.graph, capture_error_mode='thread_local'):
             with pin_stream():
-                self._phase1(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi, cs.su, cs.si, 0)
+                self._phase1(cs.u[:-1].view(pb.u_shape), cs.i[:-1].view(pb.i_shape), cs.lab, pb.pu, pb.pi, cs.su, cs.si, cs.seed)
                 if not self.split:
                     cs.out = self._phase2()
         if self.split:                                               # second graph, same memory pool, replayed in order
@@ -515,11 +521,10 @@ class FusedTrainStep:
             if pb.event is not None:
                 cur = torch.cuda.current_stream()
                 cur.wait_event(pb.event)
-                for t in (pb.packed, pb.u, pb.i, pb.lab, pb.su, pb.si):   # allocated on the upload stream, consumed here
+                for t in (pb.packed, pb.u, pb.i, pb.lab, pb.su, pb.si, pb.seed):   # allocated on the upload stream, consumed here
                     if t is not None:
                         t.record_stream(cur)
             self.n_steps += 1
-            seed = (torch.initial_seed() * 1000003 + 2 * self.n_steps) & 0x7FFFFFFFFFFFFFFF
             out = None
             if self.use_graph and pb.pi[5] and not ops.KernelTimer.enabled:
                 if self._arena_buf is not self.arena.buf:            # the arena moved: captured addresses are stale
@@ -541,6 +546,7 @@ class FusedTrainStep:
                         if cs.su is not None:
                             cs.su.copy_(pb.su, non_blocking=True)
                         cs.si.copy_(pb.si, non_blocking=True)
+                        cs.seed.copy_(pb.seed, non_blocking=True)
                     cs.graph.replay()
                     pending = self._reduce_user_part()
                     if cs.graph2 is not None:
@@ -548,7 +554,7 @@ class FusedTrainStep:
                     self.n_replays += 1
                     out = cs.out.clone().unbind(0)
             if out is None:
-                self._phase1(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si, seed)
+                self._phase1(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si, pb.seed)
                 pending = self._reduce_user_part()
                 out = self._phase2().clone().unbind(0)
             # ---- reduce + update
@@ -601,7 +607,7 @@ class FusedTrainStep:
 
 class PreparedBatch:
     """Device-resident inputs of one step + its launch plan (``FusedTrainStep.prepare``)."""
-    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'pu', 'pi', 'u_shape', 'i_shape', 'event', 'lab_cached')
+    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'seed', 'pu', 'pi', 'u_shape', 'i_shape', 'event', 'lab_cached')
 
 
 _LIVE = weakref.WeakSet()
@@ -614,4 +620,4 @@ def _drop_graphs():
 
 
 class _CapturedStep:
-    __slots__ = ('graph', 'graph2', 'packed', 'u', 'i', 'lab', 'su', 'si', 'out')
+    __slots__ = ('graph', 'graph2', 'packed', 'u', 'i', 'lab', 'su', 'si', 'seed', 'out')
