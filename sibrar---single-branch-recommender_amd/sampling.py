@@ -101,6 +101,9 @@ class DevicePositiveIndex:
         # high priority: the 10-us test kernel must not queue behind the training step's long kernels (the collate thread
         # blocks on its result two or three times per batch)
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)
+        self._host = PositiveIndex(csr)
+
+    HOST_BELOW = 1024        # queries: below this a GPU round trip (two copies + launch + sync, ~80 us) loses to numpy
 
     def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
         import torch
@@ -108,12 +111,16 @@ class DevicePositiveIndex:
         n = len(users)
         if n == 0:
             return np.zeros(0, dtype=bool)
+        if n < self.HOST_BELOW:
+            # the redraw rounds of a collate shrink geometrically (a few dozen pairs after the first): sorted-key search on
+            # the host
+            return self._host.contains(users, items)
         with torch.cuda.stream(self.stream):
-            # pageable sources: synchronous copies (see _lib.to_device)
-            u = torch.from_numpy(np.ascontiguousarray(users, dtype=np.int64)).to(self.device)
-            i = torch.from_numpy(np.ascontiguousarray(items, dtype=np.int64)).to(self.device)
+            # one pageable -> device copy for both operands (synchronous, see _lib.to_device)
+            q = torch.from_numpy(np.concatenate([np.asarray(users, dtype=np.int64), np.asarray(items, dtype=np.int64)])).to(self.device)
             out = torch.empty(n, dtype=torch.uint8, device=self.device)
-            call('sbr_csr_contains', ptr(self.indptr), ptr(self.indices), ptr(u), ptr(i), n, ptr(out), self.stream.cuda_stream)
+            call('sbr_csr_contains', ptr(self.indptr), ptr(self.indices), q.data_ptr(), q.data_ptr() + 8 * n, n, ptr(out),
+                 self.stream.cuda_stream)
             res = out.cpu()
         return res.numpy().astype(bool)
 

@@ -29,6 +29,22 @@ CFGS = {
                                'embedding_regularization_type': 'pairwise_single', 'regularization_temperature': 0.1,
                                'regularization_weight': 1e-3}},
                loss='bpr', batch=256),
+    # the shipped conf/single/algorithms/sbnet_ml1m_conf.yml: both sides entities, CSR interactions modality on both, input
+    # dropout 0.2 on the item side, no embedding regularisation, BPR, AdamW, batch 256
+    'ml1m-shipped': dict(ds=dict(n_users=5816, n_items=3299, nnz=651034, item_dense={'plot_mpnet': 768}, item_tags={'genres': (18, 3)},
+                                 user_categorical={'gender': 2, 'occupation': 21}),
+               model={'shared_common_dim': 64,
+                      'user': {'features': [{'feature_name': 'interactions', 'feature_hidden_layers': []},
+                                            {'feature_name': 'gender', 'feature_hidden_layers': []},
+                                            {'feature_name': 'occupation', 'feature_hidden_layers': []}],
+                               'single_branch_hidden_layers': [], 'preference_hidden_layers': [], 'common_modality_dim': 64,
+                               'activation_fn': 'relu', 'single_branch_input_dropout': None},
+                      'item': {'features': [{'feature_name': 'interactions', 'feature_hidden_layers': []},
+                                            {'feature_name': 'genres', 'feature_hidden_layers': []},
+                                            {'feature_name': 'plot_mpnet', 'feature_hidden_layers': []}],
+                               'single_branch_hidden_layers': [64], 'preference_hidden_layers': [], 'common_modality_dim': 64,
+                               'activation_fn': 'relu', 'single_branch_input_dropout': 0.2}},
+               loss='bpr', batch=256),
     'c3': dict(ds=dict(n_users=5192, n_items=13610, nnz=326000, item_dense={'audio': 1024}, item_tags={'genres': (853, 5)}),
                model={'shared_common_dim': 128, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
                       'item': {'features': [{'feature_name': 'interactions'}, {'feature_name': 'genres'}, {'feature_name': 'audio'}],
