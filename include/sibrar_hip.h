@@ -60,6 +60,11 @@ int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, 
  * state for high - 1 < 2^32. */
 int sbr_host_mt19937_randint(unsigned int* key, int* pos, long high, long n, long* out);
 
+/* HOST function: out[q] = (items[q] in row users[q]) over a HOST copy of the sorted interaction CSR — the membership test of
+ * the collate (data/dataloader.py:184-191) for its small redraw rounds, where a device round trip costs more than the search. */
+int sbr_host_csr_contains(const long* indptr, const int* indices, const long* users, const long* items, long n,
+                          unsigned char* out);
+
 /* Stable counting sort of the modality draw: the boolean-mask grouping of the flattened index tensor by sampled modality
  * (algorithms/sgd_alg.py:1934-1957). pos: int8 [R] modality position of every slot; segment m of slots_out
  * ([seg_offsets[m], seg_offsets[m+1]), HOST array of n_mod + 1 offsets, n_mod <= 8) receives the slots of modality m in

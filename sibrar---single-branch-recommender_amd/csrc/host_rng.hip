@@ -60,3 +60,21 @@ extern "C" int sbr_host_mt19937_randint(uint32_t* key, int* pos, long high, long
   *pos = p;
   return SBR_OK;
 }
+
+
+// Host twin of csr_contains_kernel for the small redraw rounds of the collate (a few dozen pairs: a GPU round trip costs more
+// than the search): out[q] = items[q] in row users[q] of the sorted interaction CSR (data/dataloader.py:184-191).
+extern "C" int sbr_host_csr_contains(const long* indptr, const int* indices, const long* users, const long* items, long n,
+                                     unsigned char* out) {
+  SBR_REQUIRE(indptr && indices && users && items && out, "sbr_host_csr_contains: null operand");
+  for (long q = 0; q < n; ++q) {
+    long lo = indptr[users[q]], hi = indptr[users[q] + 1];
+    const long v = items[q];
+    while (lo < hi) {
+      const long mid = (lo + hi) >> 1;
+      if (indices[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[q] = (lo < indptr[users[q] + 1] && indices[lo] == v) ? 1 : 0;
+  }
+  return SBR_OK;
+}

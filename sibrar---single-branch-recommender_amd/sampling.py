@@ -101,20 +101,28 @@ class DevicePositiveIndex:
         # high priority: the 10-us test kernel must not queue behind the training step's long kernels (the collate thread
         # blocks on its result two or three times per batch)
         self.stream = torch.cuda.Stream(device=self.device, priority=-1)
-        self._host = PositiveIndex(csr)
+        self._h_indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)       # host copy for the small redraw rounds
+        self._h_indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
 
     HOST_BELOW = 1024        # queries: below this a GPU round trip (two copies + launch + sync, ~80 us) loses to numpy
 
     def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
         import torch
-        from ._lib import call, ptr
+        from ._lib import call, lib, ptr
         n = len(users)
         if n == 0:
             return np.zeros(0, dtype=bool)
         if n < self.HOST_BELOW:
-            # the redraw rounds of a collate shrink geometrically (a few dozen pairs after the first): sorted-key search on
-            # the host
-            return self._host.contains(users, items)
+            # the redraw rounds of a collate shrink geometrically (a few dozen pairs after the first): per-row binary search on
+            # a host copy of the CSR (native, csrc/host_rng.hip)
+            u = np.ascontiguousarray(users, dtype=np.int64)
+            v = np.ascontiguousarray(items, dtype=np.int64)
+            out = np.empty(n, dtype=np.uint8)
+            rc = lib().sbr_host_csr_contains(self._h_indptr.ctypes.data, self._h_indices.ctypes.data, u.ctypes.data, v.ctypes.data,
+                                             n, out.ctypes.data)
+            if rc != 0:
+                raise RuntimeError(lib().sbr_last_error().decode())
+            return out.astype(bool)
         with torch.cuda.stream(self.stream):
             # one pageable -> device copy for both operands (synchronous, see _lib.to_device)
             q = torch.from_numpy(np.concatenate([np.asarray(users, dtype=np.int64), np.asarray(items, dtype=np.int64)])).to(self.device)
