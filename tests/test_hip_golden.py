@@ -505,3 +505,66 @@ def test_fused_step_with_input_dropout_replays_a_graph():
     a = net.get_item_representations(torch.arange(ds.n_items, device=DEV))
     b = net.get_item_representations(torch.arange(ds.n_items, device=DEV))
     assert torch.equal(a, b)
+
+
+_VARIANTS = {
+    'central_max_normalize': dict(embedding_regularization_type='central_modality', central_modality='text', aggregation_fn='max',
+                                  normalize_single_branch_input=True, regularization_temperature=0.3, regularization_weight=0.05),
+    'noreg_bn_every2_tanh_outact': dict(apply_batch_norm_every=2, apply_output_activation=True, activation_fn='tanh',
+                                        single_branch_hidden_layers=[24, 16, 16]),
+    'pairwise_nobn_sigmoid': dict(embedding_regularization_type='pairwise_single', apply_batch_normalization=False,
+                                  activation_fn='sigmoid', regularization_weight=0.1),
+    'noreg_bn_last_selu': dict(apply_batch_norm_every=-1, activation_fn='selu', single_branch_hidden_layers=[16, 16]),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', sorted(_VARIANTS))
+@pytest.mark.parametrize('user_entity', [False, True], ids=['user_lookup', 'user_entity'])
+def test_fused_step_matches_module_path_on_config_variants(variant, user_entity):
+    """engine.FusedTrainStep == the nn.Module / autograd path (pinned by the golden groups) over the entity options the shipped
+    configs use: regularisation types, max aggregation, input normalisation, BatchNorm placement (trailing / every n / last / off),
+    output activation, all four activations, tag + dense + CSR-interactions + id modalities, entity or lookup user side."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(120, 80, 2500, item_dense={'text': 12}, item_tags={'genres': (9, 3)}, user_categorical={'gender': 3},
+                            seed=6, n_negative_samples=3)
+    item = {'features': [{'feature_name': 'text', 'feature_hidden_layers': [10]}, {'feature_name': 'genres'},
+                         {'feature_name': 'interactions'}, {'feature_name': 'item_embedding'}],
+            'single_branch_hidden_layers': [16], 'preference_hidden_layers': [], 'common_modality_dim': 16}
+    item.update(_VARIANTS[variant])
+    user = ({'features': [{'feature_name': 'interactions'}, {'feature_name': 'gender'}], 'single_branch_hidden_layers': [],
+             'preference_hidden_layers': [], 'common_modality_dim': 16, 'embedding_regularization_type': 'pairwise_single',
+             'regularization_weight': 0.02} if user_entity else {'feature_name': 'user_embedding', 'embedding_dim': -1})
+    cfg = {'shared_common_dim': 16, 'user': user, 'item': item}
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(21)
+        np.random.seed(21)
+        nets.append(S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV).train())
+    opts = [S.FusedOptimizer(n_, 'adamw', lr=1e-2, weight_decay=1e-3) for n_ in nets]
+    lossf = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+    fused = S.FusedTrainStep(nets[1], lossf, opts[1])
+    rng = np.random.default_rng(8)
+    for s_ in range(4):
+        u = torch.from_numpy(rng.integers(0, ds.n_users, size=40))
+        i = torch.from_numpy(rng.integers(0, ds.n_items, size=(40, 4)))
+        labels = torch.zeros(40, 4, dtype=torch.float64)
+        labels[:, 0] = 1
+        logits = nets[0](u.to(DEV), i.to(DEV))
+        loss = lossf.compute_loss(logits, labels.to(DEV))
+        reg = nets[0].get_and_reset_other_loss()['reg_loss']
+        (loss + reg.to(loss.device).sum()).backward()
+        opts[0].step()
+        opts[0].zero_grad()
+        total, rec, reg2 = fused.step(u, i, labels)
+        close(rec.cpu(), loss.detach().cpu().double(), what=f'rec loss step {s_}', rtol=2e-5, atol=1e-7)
+        close(reg2.cpu().reshape(-1), reg.detach().cpu().double().reshape(-1), what=f'reg loss step {s_}', rtol=2e-5, atol=1e-7)
+    nets[1].check_index_errors()
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    # zero-gradient parameters (Adam turns rounding noise into +-lr steps): biases in front of a BatchNorm, and the shift of a
+    # BatchNorm that ends the item network — BPR differences cancel a common shift of all item representations
+    skip = set(bn_shadowed_biases(sd0.keys())) | {'item_embedding_module.sb_net.1.bias',
+                                                  'item_embedding_module.sb_net.0.layers.batch_norm.bias'}
+    for k in sd0:
+        if k not in skip:
+            close(sd1[k].cpu(), sd0[k].cpu(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)
