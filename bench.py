@@ -295,10 +295,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # SBR_DIST_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-process path on a one-GPU box (ranks share cuda:0,
+    # collectives staged through the host) — never a reportable number
+    backend = os.environ.get('SBR_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = f'cuda:{local}'
     torch.cuda.set_device(local)
@@ -321,6 +328,16 @@ def main():
                    'batch_per_gpu': args.batch_size, 'global_batch': args.batch_size * world, 'n_negatives': cfg['n_neg'],
                    'parallelism': f'dp{world}' if world > 1 else 'single', 'settle_steps': SETTLE},
     }
+    if world > 1:
+        # data-parallel sanity: after identical initialisation and all-reduced gradients every replica must hold the same
+        # trainable parameters (BatchNorm running statistics are rank-local by design and are not parameters)
+        with torch.no_grad():
+            chk = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in net.parameters()]).sum(),
+                               torch.cat([p.detach().double().abs().reshape(-1) for p in net.parameters()]).sum()])
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            out['config']['replica_param_checksum_spread'] = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
     roof = dominant_gemm(timings, args.steps) if rank == 0 else None
     if roof:
         out['roofline'] = roof
