@@ -10,6 +10,11 @@
 #define LOSS_BPR 1
 #define LOSS_SSM 2
 
+// loss scalars are zeroed by a one-thread kernel, not by hipMemsetAsync: inside a replayed hipGraph the 8-byte memset node was
+// observed to stop taking effect while another host thread issued copies (the scalar then kept a stale value for every later
+// replay); a kernel node has no such dependence on the runtime's fill path.
+__global__ void zero_f64_kernel(double* __restrict__ p) { p[0] = 0.0; }
+
 __device__ __forceinline__ double block_sum_d(double v, double* sm) {
   v = sbr_wave_sum_d(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -85,7 +90,7 @@ extern "C" int sbr_rec_loss_fwd(int kind, const float* logits, const double* lab
   SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_fwd: unknown loss kind %d", kind);
   SBR_REQUIRE(logits && loss_out && (kind == LOSS_SSM || labels), "sbr_rec_loss_fwd: null operand");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_rec_loss_fwd: memset failed"); return SBR_ERR_HIP; }
+  zero_f64_kernel<<<1, 1, 0, s>>>(loss_out);
   if (B == 0) return SBR_OK;
   rec_loss_kernel<false><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, nullptr);
   SBR_CHECK_LAUNCH("sbr_rec_loss_fwd");
@@ -180,7 +185,7 @@ extern "C" int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, 
   SBR_REQUIRE(A && B && loss_out, "sbr_infonce_fwd: null operand");
   SBR_REQUIRE(N >= 1 && N <= INFONCE_MAX_N, "sbr_infonce_fwd: N=%d outside [1, %d]", N, INFONCE_MAX_N);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_infonce_fwd: memset failed"); return SBR_ERR_HIP; }
+  zero_f64_kernel<<<1, 1, 0, s>>>(loss_out);
   if (G == 0) return SBR_OK;
   const int lds = infonce_lds(N);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)infonce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -280,7 +285,7 @@ extern "C" int sbr_infonce_gemm_fwd(const float* A, const float* B, long ld, lon
   SBR_REQUIRE(N >= 1 && D >= 1, "sbr_infonce_gemm_fwd: bad shape");
   SBR_REQUIRE(workspace && workspace_bytes >= sbr_infonce_gemm_workspace(N, D), "sbr_infonce_gemm_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_out, 0, sizeof(double), s) != hipSuccess) { sbr_set_error("sbr_infonce_gemm_fwd: memset failed"); return SBR_ERR_HIP; }
+  zero_f64_kernel<<<1, 1, 0, s>>>(loss_out);
   float* S = (float*)workspace;
   float* lse_r = S + (long)N * N;
   float* lse_c = lse_r + N;
