@@ -32,6 +32,7 @@ PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_MFMA_F16 = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM = 8000.0         # GB/s
 SETTLE = 30               # extra untimed steps after --warmup (see bench_training)
+LAST_LOSS = {}            # batch size -> total loss of the last timed step
 
 C2 = dict(n_users=100_000, n_items=50_000, nnz=5_000_000, feat_dim=768, emb_dim=128, n_neg=10)
 
@@ -69,8 +70,10 @@ def epochs(loader):
 
 
 def run_steps(S, trainer, loader_iter, n, world):
+    out = None
     for _ in range(n):
-        trainer.train_step(*next(loader_iter))
+        out = trainer.train_step(*next(loader_iter))
+    return out
 
 
 def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_kernels):
@@ -99,11 +102,14 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    run_steps(S, trainer, it, steps, world)
+    last = run_steps(S, trainer, it, steps, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    LAST_LOSS[batch] = float(last[0]) if last is not None else None      # sanity of the timed steps (read after the clock)
+    if LAST_LOSS[batch] is not None and not (0.0 < LAST_LOSS[batch] < 1e3):
+        raise RuntimeError(f'training loss after the timed region is {LAST_LOSS[batch]}: the timed steps did not train')
     timings = {}
     if time_kernels:
         # per-kernel HIP events cannot be recorded inside a hipGraph replay: the next `steps` batches of the same loader are
@@ -326,7 +332,8 @@ def main():
                                'sampled-softmax, 10 negatives, AdamW; user = embedding lookup, item = SingleBranchNet entity '
                                '(text 768-d + item-id embedding, hidden [128], BatchNorm)' + (' [SMALL DEBUG SIZE]' if args.small else ''),
                    'batch_per_gpu': args.batch_size, 'global_batch': args.batch_size * world, 'n_negatives': cfg['n_neg'],
-                   'parallelism': f'dp{world}' if world > 1 else 'single', 'settle_steps': SETTLE},
+                   'parallelism': f'dp{world}' if world > 1 else 'single', 'settle_steps': SETTLE,
+                   'loss_after_timed_steps': LAST_LOSS.get(args.batch_size)},
     }
     if world > 1:
         # data-parallel sanity: after identical initialisation and all-reduced gradients every replica must hold the same
