@@ -265,7 +265,7 @@ class _EntityRun:
             call('sbr_l2norm_bwd', ptr(d), ptr(self.xn), ptr(self.inv), ptr(dn), R, self.C, ops.NORM_EPS, st)
             d = dn
         if d.data_ptr() != dx0.data_ptr():               # no layer at all: the incoming gradient is the matrix gradient
-            dx0[:R].copy_(d)
+            torch.mul(d, 1.0, out=dx0[:R])                # a kernel node, not a memcpy node (see DESIGN.md §5 on memset nodes)
         d = dx0
         for (fe, o, n), hs in zip(self.entries, self.hidden):
             ps = fe.front_params()
