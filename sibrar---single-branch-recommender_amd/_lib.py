@@ -104,13 +104,21 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_STREAM = [None]
+import threading
+
+
+class _PinnedStream(threading.local):
+    """Per-thread pinned stream handle (the loader threads and the launch thread must never see each other's)."""
+    value = None
+
+
+_STREAM = _PinnedStream()
 
 
 def stream():
     """hipStream_t of torch's current stream. ``pin_stream`` caches it for the duration of a fused step."""
-    if _STREAM[0] is not None:
-        return _STREAM[0]
+    if _STREAM.value is not None:
+        return _STREAM.value
     import torch
     return torch.cuda.current_stream().cuda_stream
 
@@ -120,12 +128,12 @@ class pin_stream:
 
     def __enter__(self):
         import torch
-        self.prev = _STREAM[0]
-        _STREAM[0] = torch.cuda.current_stream().cuda_stream
-        return _STREAM[0]
+        self.prev = _STREAM.value
+        _STREAM.value = torch.cuda.current_stream().cuda_stream
+        return _STREAM.value
 
     def __exit__(self, *exc):
-        _STREAM[0] = self.prev
+        _STREAM.value = self.prev
         return False
 
 
