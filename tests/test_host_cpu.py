@@ -213,7 +213,11 @@ print('rank', rank, 'ok')
 def test_two_rank_gloo_data_parallel_and_item_sharding(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', WORLD_SIZE='2')
+    import socket
+    with socket.socket() as sock:                     # a free port (a fixed one collides with lingering sockets of earlier runs)
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
