@@ -3,9 +3,14 @@ launches — forward, losses, hand-written backward, gradient all-reduce, fused 
 tape, without per-op tensor allocation and without a host sync.
 
 It computes exactly what ``loss(model(u, i)).backward(); optimizer.step()`` computes through the ``nn.Module`` surface
-(``tests/test_hip_golden.py::test_fused_step_matches_autograd_path`` checks parameters after several steps): the modules
-keep owning the parameters (flat buffer of ``optim.FlatParameters``), this class only replaces the launch choreography.
-Per step the host does: the modality draw + counting sort (numpy), three index uploads, ~120 ctypes calls.
+(``tests/test_hip_golden.py::test_fused_step_matches_autograd_path`` and ``..._on_config_variants`` check losses and
+parameters after several steps): the modules keep owning the parameters (flat buffer of ``optim.FlatParameters``), this class
+only replaces the launch choreography.
+
+Host work per step is split in two: ``prepare`` (modality draw, per-modality counts, one packed upload — normally on the
+loader thread, ahead of time) and ``step`` (wait for the upload's event, copy it into the captured graph's static buffers,
+replay forward + backward as a hipGraph, gradient exchange, one fused optimizer launch). Signatures that have not been
+captured yet run the same launches one by one (~120 ctypes calls).
 
 Supported (everything the shipped sbnet configurations use): user side = embedding lookup / any plain FeatureEmbedding or a
 SingleBranchNetEntity; item side = SingleBranchNetEntity; rec losses bce / bpr / sampled softmax; InfoNCE regularisation.
