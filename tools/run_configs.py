@@ -45,6 +45,13 @@ CFGS = {
                                'single_branch_hidden_layers': [64], 'preference_hidden_layers': [], 'common_modality_dim': 64,
                                'activation_fn': 'relu', 'single_branch_input_dropout': 0.2}},
                loss='bpr', batch=256),
+    # BASELINE c4 shape on ONE GPU (the 8-GPU run shards the batch): 1M users x 200k items, text 768 + image 2048, D = 256,
+    # user = embedding lookup; 20M interactions keep the host-side generation short
+    'c4': dict(ds=dict(n_users=1_000_000, n_items=200_000, nnz=20_000_000, item_dense={'text': 768, 'image': 2048}),
+               model={'shared_common_dim': 256, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+                      'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'image'}],
+                               'single_branch_hidden_layers': [256], 'preference_hidden_layers': [], 'common_modality_dim': 256}},
+               loss='ssm', batch=256),
     'c3': dict(ds=dict(n_users=5192, n_items=13610, nnz=326000, item_dense={'audio': 1024}, item_tags={'genres': (853, 5)}),
                model={'shared_common_dim': 128, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
                       'item': {'features': [{'feature_name': 'interactions'}, {'feature_name': 'genres'}, {'feature_name': 'audio'}],
