@@ -163,6 +163,9 @@ int sbr_rec_loss_fwd(int kind, const float* logits, const double* labels, long B
                      double* loss_out, void* stream);
 int sbr_rec_loss_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
                      const void* grad_out, int grad_out_is_double, float* dlogits, void* stream);
+/* both in one pass with upstream gradient 1 (the training step: total.backward() of train/trainer.py:213-221) */
+int sbr_rec_loss_fwd_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                         double* loss_out, float* dlogits, void* stream);
 
 /* InfoNCE.forward — train/regularization_losses.py:14-43, called from algorithms/sgd_alg.py:1989 on e[..., 0, :] and
  * e[..., 1, :]. G groups of N rows, row stride ld; N <= sbr_infonce_max_n(). scale = 1/(G*N) for 'mean'. */

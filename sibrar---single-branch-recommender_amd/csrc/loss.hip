@@ -31,21 +31,22 @@ __device__ __forceinline__ double bce_term(double x, double y) { return fmax(x, 
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // one thread per batch row
-template <bool BWD>
+template <int MODE>   // 0: loss, 1: gradient, 2: both (upstream gradient 1: the fused training step)
 __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, const double* __restrict__ labels, long B, int N,
                                 double scale, float shift, double* __restrict__ loss_out, const void* __restrict__ gout,
                                 int gout_is_double, float* __restrict__ dlogits) {
   const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
   double acc = 0.0;
-  double up = 1.0;
-  if (BWD) up = (gout_is_double ? ((const double*)gout)[0] : (double)((const float*)gout)[0]) * scale;
+  constexpr bool FWD = MODE != 1, BWD = MODE != 0;
+  double up = scale;
+  if (MODE == 1) up = (gout_is_double ? ((const double*)gout)[0] : (double)((const float*)gout)[0]) * scale;
   if (b < B) {
     const float* x = logits + b * N;
     if (kind == LOSS_BCE) {
       for (int j = 0; j < N; ++j) {
         const double xv = (double)x[j], y = labels[b * N + j];
-        if (!BWD) acc += bce_term(xv, y);
-        else dlogits[b * N + j] = (float)(up * (sigmoid_d(xv) - y));
+        if (FWD) acc += bce_term(xv, y);
+        if (BWD) dlogits[b * N + j] = (float)(up * (sigmoid_d(xv) - y));
       }
     } else if (kind == LOSS_BPR) {
       // rec_losses.py:73-81: diff = pos - neg (float32), target = label of the positive column
@@ -53,8 +54,8 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
       double gpos = 0.0;
       for (int j = 1; j < N; ++j) {
         const double d = (double)(x[0] - x[j]);
-        if (!BWD) acc += bce_term(d, y);
-        else {
+        if (FWD) acc += bce_term(d, y);
+        if (BWD) {
           const double gd = up * (sigmoid_d(d) - y);
           gpos += gd;
           dlogits[b * N + j] = (float)(-gd);
@@ -68,8 +69,8 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
       float se = expf(x[0] - mx);
       for (int j = 1; j < N; ++j) se += expf(x[j] + shift - mx);
       const float lse = mx + logf(se);
-      if (!BWD) acc += (double)(lse - x[0]);
-      else {
+      if (FWD) acc += (double)(lse - x[0]);
+      if (BWD) {
         for (int j = 0; j < N; ++j) {
           const float p = expf(x[j] + (j ? shift : 0.f) - lse);
           dlogits[b * N + j] = (float)(up * (double)(p - (j == 0 ? 1.f : 0.f)));
@@ -77,7 +78,7 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
       }
     }
   }
-  if (!BWD) {
+  if (FWD) {
     __shared__ double sm[4];
     const double t = block_sum_d(acc, sm);
     if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
@@ -92,7 +93,7 @@ extern "C" int sbr_rec_loss_fwd(int kind, const float* logits, const double* lab
   hipStream_t s = (hipStream_t)stream;
   zero_f64_kernel<<<1, 1, 0, s>>>(loss_out);
   if (B == 0) return SBR_OK;
-  rec_loss_kernel<false><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, nullptr);
+  rec_loss_kernel<0><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, nullptr);
   SBR_CHECK_LAUNCH("sbr_rec_loss_fwd");
   return SBR_OK;
 }
@@ -102,9 +103,22 @@ extern "C" int sbr_rec_loss_bwd(int kind, const float* logits, const double* lab
   SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_bwd: unknown loss kind %d", kind);
   SBR_REQUIRE(logits && grad_out && dlogits && (kind == LOSS_SSM || labels), "sbr_rec_loss_bwd: null operand");
   if (B == 0) return SBR_OK;
-  rec_loss_kernel<true><<<sbr_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(kind, logits, labels, B, N, scale, shift, nullptr,
+  rec_loss_kernel<1><<<sbr_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(kind, logits, labels, B, N, scale, shift, nullptr,
                                                                            grad_out, grad_out_is_double, dlogits);
   SBR_CHECK_LAUNCH("sbr_rec_loss_bwd");
+  return SBR_OK;
+}
+
+// loss and d loss / d logits in one pass (upstream gradient 1): what a training step needs (trainer.py:213-221)
+extern "C" int sbr_rec_loss_fwd_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                                    double* loss_out, float* dlogits, void* stream) {
+  SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_fwd_bwd: unknown loss kind %d", kind);
+  SBR_REQUIRE(logits && loss_out && dlogits && (kind == LOSS_SSM || labels), "sbr_rec_loss_fwd_bwd: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  zero_f64_kernel<<<1, 1, 0, s>>>(loss_out);
+  if (B == 0) return SBR_OK;
+  rec_loss_kernel<2><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, dlogits);
+  SBR_CHECK_LAUNCH("sbr_rec_loss_fwd_bwd");
   return SBR_OK;
 }
 

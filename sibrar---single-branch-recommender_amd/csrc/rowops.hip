@@ -91,11 +91,12 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const signed cha
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < SBR_PART_MAX) {
     int bsum = 0, tsum = 0;
-    for (int b = 0; b < (int)gridDim.x; ++b) {
-      const int v = hist[b * SBR_PART_MAX + t];
-      if (b < (int)blockIdx.x) bsum += v;
-      tsum += v;
-    }
+    if (hist)                       // hist == nullptr: one block covers all slots and takes the totals from its own scan below
+      for (int b = 0; b < (int)gridDim.x; ++b) {
+        const int v = hist[b * SBR_PART_MAX + t];
+        if (b < (int)blockIdx.x) bsum += v;
+        tsum += v;
+      }
     before[t] = bsum;
     total[t] = tsum;
   }
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const signed cha
     if (lane == 63) wave_tot[m][wave] = incl;
   }
   __syncthreads();
+  if (!hist && t < SBR_PART_MAX) total[t] = wave_tot[t][0] + wave_tot[t][1] + wave_tot[t][2] + wave_tot[t][3];
 #pragma unroll
   for (int m = 0; m < SBR_PART_MAX; ++m) {
     int w = (m < sg.n_mod ? sg.offs[m] : 0) + before[m] + excl[m];
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const signed cha
       if (mine[e] == q) slots_out[excl[q]++] = (int)(lo + e);
   }
   // padding tails [offs[m] + total[m], offs[m+1]) <- R, shared by all blocks
+  if (!hist) __syncthreads();      // single-block mode: total[] was written after the barrier above
   for (int m = 0; m < sg.n_mod; ++m) {
     const int beg = sg.offs[m] + total[m], end = sg.offs[m + 1];
     for (int e = beg + blockIdx.x * 256 + t; e < end; e += gridDim.x * 256) slots_out[e] = (int)R;
@@ -157,8 +160,12 @@ extern "C" int sbr_partition_slots(const signed char* pos, long R, int n_mod, co
   if (sg.offs[n_mod] == 0) return SBR_OK;
   const int nb = sbr_cdiv(R > 0 ? R : 1, PART_CHUNK);
   hipStream_t s = (hipStream_t)stream;
-  partition_count_kernel<<<nb, 256, 0, s>>>(pos, R, n_mod, (int*)workspace);
-  partition_scatter_kernel<<<nb, 256, 0, s>>>(pos, R, sg, (const int*)workspace, slots_out);
+  if (nb == 1) {                   // small batches: one launch (the kernel chain, not the work, bounds them)
+    partition_scatter_kernel<<<1, 256, 0, s>>>(pos, R, sg, nullptr, slots_out);
+  } else {
+    partition_count_kernel<<<nb, 256, 0, s>>>(pos, R, n_mod, (int*)workspace);
+    partition_scatter_kernel<<<nb, 256, 0, s>>>(pos, R, sg, (const int*)workspace, slots_out);
+  }
   SBR_CHECK_LAUNCH("sbr_partition_slots");
   return SBR_OK;
 }

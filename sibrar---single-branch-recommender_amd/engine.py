@@ -377,9 +377,8 @@ class FusedTrainStep:
             scale = 1.0 / B if rl.aggregator == 'mean' else 1.0
         shift = math.log(rl.n_items / rl.neg_train) if (self.kind == 2 and rl.train_neg_strategy == 'uniform') else 0.0
         loss = a.f64()
-        call('sbr_rec_loss_fwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), st)
         dlog = a.f32(B, N)
-        call('sbr_rec_loss_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(self.one64), 1, ptr(dlog), st)
+        call('sbr_rec_loss_fwd_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog), st)
         dU, dI = a.f32(B, D), a.f32(B * N, D)
         call('sbr_score_dot_bwd', ptr(dlog), ptr(ur), ptr(ir), ptr(dU), ptr(dI), B, N, D, st)
         self.user.backward(dU, self.one32)
