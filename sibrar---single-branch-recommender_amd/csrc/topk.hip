@@ -34,9 +34,11 @@ __device__ __forceinline__ float key2f(unsigned int k) {
 
 #define TOPK_MAX 256
 
-// one 256-thread workgroup per row: 4-pass 8-bit radix select of the k-th largest key, ordered collection, bitonic sort
-__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, long ld, int I, int k, int kpad,
-                                                        float* __restrict__ out_val, int* __restrict__ out_idx) {
+// Exact selection by radix: 4-pass 8-bit radix select of the k-th largest key (six reads of the row in total), ordered
+// collection, bitonic sort. One 256-thread workgroup per row. Used directly for short rows and as the fallback of the sampled
+// kernel below.
+__device__ __forceinline__ void topk_row_radix(const float* __restrict__ S, long ld, int I, int k, int kpad,
+                                               float* __restrict__ out_val, int* __restrict__ out_idx) {
   __shared__ unsigned int hist[256];
   __shared__ unsigned long long cand[TOPK_MAX];
   __shared__ unsigned int s_prefix, s_need, s_cnt, s_wave[4], s_taken;
@@ -124,6 +126,118 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, long ld, int I, int k, int kpad,
+                                                        float* __restrict__ out_val, int* __restrict__ out_idx) {
+  topk_row_radix(S, ld, I, k, kpad, out_val, out_idx);
+}
+
+// Long rows (the [users, items] score matrix of the fp32 evaluation path is read from HBM, 200 KB per row at 50k items): the
+// radix select above reads a row six times. Here a 1/16 sample of the row (kept in LDS) yields a threshold T0 whose rank in the
+// whole row is ~4k +- 20 %; ONE full read then collects every element >= T0 (a few hundred) into an LDS buffer, which is
+// sorted exactly (score descending, index ascending — the same composite key as everywhere). The result is exact whenever
+// k <= #collected <= TOPK_CAND, which the kernel checks; otherwise (heavy ties, adversarial rows) the row takes the radix path.
+#define TOPK_SAMPLE_STRIDE 16
+#define TOPK_SAMPLE_MAX 4096
+#define TOPK_CAND 2048
+
+__global__ __launch_bounds__(256) void topk_rows_sampled_kernel(const float* __restrict__ S, long ld, int I, int k, int kpad,
+                                                                float* __restrict__ out_val, int* __restrict__ out_idx) {
+  __shared__ unsigned int samp[TOPK_SAMPLE_MAX];
+  __shared__ unsigned long long cand[TOPK_CAND];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int s_prefix, s_need, s_cnt;
+  const float* row = S + blockIdx.x * ld;
+  const int t = threadIdx.x;
+  const int ns = (I + TOPK_SAMPLE_STRIDE - 1) / TOPK_SAMPLE_STRIDE;          // <= TOPK_SAMPLE_MAX (checked by the launcher)
+  for (int j = t; j < ns; j += 256) samp[j] = f2key(row[(long)j * TOPK_SAMPLE_STRIDE]);
+  // rank of T0 in the sample: m-th largest, m ~ 4k / stride (at least 4): its rank in the row is ~ m * stride
+  int m = (4 * k + TOPK_SAMPLE_STRIDE - 1) / TOPK_SAMPLE_STRIDE;
+  m = m < 4 ? 4 : m;
+  m = m > ns ? ns : m;
+  unsigned int prefix = 0, need = (unsigned)m;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[t] = 0;
+    __syncthreads();
+    const unsigned int hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int j = t; j < ns; j += 256) {
+      const unsigned int key = samp[j];
+      if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned int acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      s_prefix = prefix | ((unsigned)d << shift);
+      s_need = need - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    __syncthreads();
+  }
+  const unsigned int T0 = prefix;                    // m-th largest sample key
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  // one pass over the row: everything >= T0 (float4 loads when the row is 16-byte aligned)
+  const bool vec = ((((uintptr_t)row) & 15) == 0);
+  const int I4 = vec ? (I >> 2) : 0;
+  for (int q = t; q < I4; q += 256) {
+    const float4 v = reinterpret_cast<const float4*>(row)[q];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned int key = f2key(e[c]);
+      if (key >= T0) {
+        const unsigned int pos = atomicAdd(&s_cnt, 1u);
+        if (pos < TOPK_CAND) cand[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(4 * q + c));
+      }
+    }
+  }
+  for (int i = 4 * I4 + t; i < I; i += 256) {
+    const unsigned int key = f2key(row[i]);
+    if (key >= T0) {
+      const unsigned int pos = atomicAdd(&s_cnt, 1u);
+      if (pos < TOPK_CAND) cand[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+  }
+  __syncthreads();
+  const unsigned int n = s_cnt;
+  if (n < (unsigned)k || n > TOPK_CAND) {            // uniform per workgroup: exact fallback
+    __syncthreads();
+    topk_row_radix(S, ld, I, k, kpad, out_val, out_idx);
+    return;
+  }
+  // bitonic sort (descending) of the candidates, padded with zeros to a power of two >= n
+  int np = 2;
+  while (np < (int)n) np <<= 1;
+  for (int i = (int)n + t; i < np; i += 256) cand[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < np; i += 256) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = (i & size) == 0;
+          const unsigned long long a = cand[i], b = cand[j];
+          if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < k) {
+    const unsigned long long c = cand[t];
+    out_val[blockIdx.x * (long)k + t] = key2f((unsigned int)(c >> 32));
+    out_idx[blockIdx.x * (long)k + t] = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
+  }
+}
+
 extern "C" int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k, float* out_val, int* out_idx, void* stream) {
   SBR_REQUIRE(k >= 1 && k <= TOPK_MAX, "sbr_topk_rows: k=%d outside [1, %d]", k, TOPK_MAX);
   SBR_REQUIRE(k <= I, "sbr_topk_rows: k=%d larger than the row length %d", k, I);
@@ -131,7 +245,11 @@ extern "C" int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k
   SBR_REQUIRE(scores && out_val && out_idx, "sbr_topk_rows: null operand");
   int kpad = 2;
   while (kpad < k) kpad <<= 1;
-  topk_rows_kernel<<<(unsigned)Bu, 256, 0, (hipStream_t)stream>>>(scores, ld, I, k, kpad, out_val, out_idx);
+  // long rows: one-read sampled selection; short rows (or k close to the candidate capacity): radix select
+  if (I >= 8192 && I <= TOPK_SAMPLE_MAX * TOPK_SAMPLE_STRIDE && 8 * k <= TOPK_CAND)
+    topk_rows_sampled_kernel<<<(unsigned)Bu, 256, 0, (hipStream_t)stream>>>(scores, ld, I, k, kpad, out_val, out_idx);
+  else
+    topk_rows_kernel<<<(unsigned)Bu, 256, 0, (hipStream_t)stream>>>(scores, ld, I, k, kpad, out_val, out_idx);
   SBR_CHECK_LAUNCH("sbr_topk_rows");
   return SBR_OK;
 }

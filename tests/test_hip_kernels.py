@@ -395,3 +395,32 @@ def test_partition_slots_is_a_stable_counting_sort(R, n_mod, pad):
     call('sbr_partition_slots', ptr(pos_d), R, n_mod, ctypes.cast(seg_arr, ctypes.c_void_p), ptr(out), ptr(ws), ws.numel() * 4,
          ops.stream())
     assert np.array_equal(out.cpu().numpy()[:int(seg[-1])], want)
+
+
+@pytest.mark.parametrize('I', [8192, 50000, 65536])
+def test_topk_long_rows_sampled_path_is_exact(I):
+    """Rows of >= 8192 scores take the one-read sampled selection (threshold from a 1/16 sample, one pass collecting everything
+    above it, exact sort of the few hundred candidates). It must return exactly what the radix path returns: same values, ties
+    towards the lower index — also for rows that force its fallback (mostly masked rows, constant rows, heavy ties)."""
+    ops = S().ops
+    g = torch.Generator().manual_seed(71 + I)
+    sc = torch.randn(24, I, generator=g)
+    n3 = (I - 2) // 3
+    sc[1, 0:3 * n3:3] = sc[1, 1:3 * n3:3]                # many exact ties
+    sc[2] = 0.5                                          # constant row: every element ties with the threshold -> fallback
+    sc[3] = -float('inf')
+    sc[3, 17] = 3.0                                      # fewer finite values than k -> fallback
+    sc[4, :I // 2] = -float('inf')                       # half masked
+    sc[5] = torch.arange(I, dtype=torch.float32)         # sorted ascending (the sample sees every 16th)
+    sc[6] = -torch.arange(I, dtype=torch.float32)
+    sc[7] = torch.randn(I, generator=g).abs() * 1e-30    # tiny magnitudes (denormal range of the key space)
+    d = sc.to(DEV)
+    for k in (1, 10, 100, 256):
+        val, idx = ops.topk_rows(d, k)
+        tv, _ = torch.topk(sc, k, sorted=True)
+        assert torch.equal(val.cpu(), tv), (I, k)
+        srt = idx.cpu().long()
+        assert torch.equal(torch.gather(sc, 1, srt), val.cpu())
+        assert all(len(set(r.tolist())) == k for r in srt)
+        same = val[:, 1:].cpu() == val[:, :-1].cpu()
+        assert (srt[:, 1:][same] > srt[:, :-1][same]).all()
