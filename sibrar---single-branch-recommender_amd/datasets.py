@@ -136,6 +136,10 @@ class NegativeSamplingDataLoader:
         self.positives = (DevicePositiveIndex(dataset.user_sampling_matrix, device) if device is not None
                           else PositiveIndex(dataset.user_sampling_matrix))
         self.rank, self.world, self.max_batches = rank, world, max_batches
+        self._device = None
+        if device is not None:
+            d = torch.device(device)
+            self._device = torch.device('cuda', d.index if d.index is not None else torch.cuda.current_device())
         if dp_sampling not in ('global', 'local'):
             raise ValueError(f'dp_sampling {dp_sampling!r}')
         self.dp_sampling = dp_sampling
@@ -172,6 +176,10 @@ class NegativeSamplingDataLoader:
 
         def stage(source, sink, fn):
             try:
+                # the HIP current device is per thread (a new thread starts on device 0): kernels and copies of this thread
+                # must be issued with the loader's device current — rank r of a multi-GPU job drives cuda:r
+                if self._device is not None and torch.cuda.is_available():
+                    torch.cuda.set_device(self._device)
                 for b in source:
                     if stop.is_set() or not put(sink, fn(b)):
                         return

@@ -126,7 +126,7 @@ class DevicePositiveIndex:
             if rc != 0:
                 raise RuntimeError(lib().sbr_last_error().decode())
             return out.astype(bool)
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             # one pageable -> device copy for both operands (synchronous, see _lib.to_device)
             q = torch.from_numpy(np.concatenate([np.asarray(users, dtype=np.int64), np.asarray(items, dtype=np.int64)])).to(self.device)
             out = torch.empty(n, dtype=torch.uint8, device=self.device)
