@@ -297,15 +297,21 @@ def main():
     import torch.distributed as dist
     if 'SBR_SWITCH_INTERVAL' in os.environ:
         sys.setswitchinterval(float(os.environ['SBR_SWITCH_INTERVAL']))
-    torch.set_num_threads(host_cores())      # torch CPU ops of the loader threads: stay inside the job's CPU quota
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # torch CPU ops of the loader threads: stay inside the job's CPU quota, shared by the ranks of the node
+    torch.set_num_threads(max(1, host_cores() // int(os.environ.get('LOCAL_WORLD_SIZE', world))))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     # SBR_DIST_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-process path on a one-GPU box (ranks share cuda:0,
     # collectives staged through the host) — never a reportable number
     backend = os.environ.get('SBR_DIST_BACKEND', 'nccl')
     local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # SBR_FORCE_DIST=1: one-rank process group with the gradient / top-k exchange switched on (rehearsal of the RCCL call
+    # sequence on a one-GPU box — never a reportable number)
+    force_dist = world == 1 and os.environ.get('SBR_FORCE_DIST', '0') == '1'
+    if force_dist:
+        os.environ.setdefault('MASTER_PORT', '29517')
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
         if backend == 'nccl':
@@ -361,7 +367,7 @@ def main():
         out['cpu_baseline']['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -10,6 +10,7 @@ One process per GPU; ``backend='nccl'`` is RCCL on ROCm, ``gloo`` is used by the
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -17,7 +18,11 @@ import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients / top-k lists are exchanged. ``SBR_FORCE_DIST=1`` turns the exchange on for a one-rank process
+    group as well (test aid: the RCCL call sequence of a data-parallel step on a one-GPU box; sum over one rank / 1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('SBR_FORCE_DIST', '0') == '1'
 
 
 def shard_batch(u_idxs, i_idxs, labels, rank: int = None, world: int = None):

@@ -327,6 +327,66 @@ def test_fused_step_graph_replay_equals_plain_launches(split, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_data_parallel_step_over_rccl_one_rank(monkeypatch, tmp_path):
+    """The data-parallel step with the real RCCL backend on the one GPU of the test box: a one-rank ``nccl`` process group and
+    SBR_FORCE_DIST=1 make the engine run its multi-GPU launch structure (two graphs, asynchronous all-reduce of the user part
+    on RCCL's stream between them, all-reduce of the rest, wait on the compute stream, division by the world size) and the
+    item-sharded scoring its top-k all-gather + merge. Summing over one rank changes nothing, so losses, parameters and
+    top-k lists must equal the run without a process group. (More ranks need more GPUs: the driver's scaling run.)"""
+    import torch.distributed as dist
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
+    cfg = {'shared_common_dim': 64, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [64], 'preference_hidden_layers': [], 'common_modality_dim': 64}}
+
+    def run():
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+        net.train()
+        opt = S.FusedOptimizer(net, 'adamw', lr=1e-2, weight_decay=1e-2)
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+        fused = S.FusedTrainStep(net, loss, opt, use_graph=True)
+        rng = np.random.default_rng(9)
+        losses = []
+        for s_ in range(10):
+            u = torch.from_numpy(rng.integers(0, ds.n_users, size=64))
+            i = torch.from_numpy(rng.integers(0, ds.n_items, size=(64, 4)))
+            labels = torch.zeros(64, 4, dtype=torch.float64)
+            labels[:, 0] = 1
+            losses.append(torch.stack(fused.step(u, i, labels)).cpu())
+        net.eval()
+        with torch.no_grad():
+            i16 = S.ops.cast_f16(net.get_item_representations(torch.arange(ds.n_items, device=DEV)))
+            users = torch.arange(ds.n_users, device=DEV)
+            u16 = S.ops.cast_f16(net.get_user_representations(users))
+            val0, idx0 = S.ops.score_topk_f16(u16, i16, 10, users, None, None, item_offset=0)
+            val, idx = S.parallel.all_gather_topk(val0, idx0, 10)         # one shard: the merge must return the list itself
+        torch.cuda.synchronize()
+        fused.close()
+        assert torch.equal(val, val0) and torch.equal(idx.to(idx0.dtype), idx0)
+        return fused, losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+
+    monkeypatch.setenv('SBR_FORCE_SPLIT', '1')
+    plain = run()
+    monkeypatch.setenv('SBR_FORCE_DIST', '1')
+    dist.init_process_group('nccl', init_method=f'file://{tmp_path}/rdzv', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        assert S.parallel.is_distributed()
+        rccl = run()
+    finally:
+        dist.destroy_process_group()
+    assert rccl[0].split and rccl[0].n_replays >= 4
+    for s_, (a, b) in enumerate(zip(plain[1], rccl[1])):
+        close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
+    skip = set(bn_shadowed_biases(plain[2].keys())) | {'item_embedding_module.sb_net.1.bias'}
+    for k in plain[2]:
+        if k not in skip:
+            close(rccl[2][k].double(), plain[2][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)
+
+
+@pytest.mark.gpu
 def test_loader_pipeline_equals_inline_steps():
     """Batches prepared ahead by the loader's two producer threads (collate -> FusedTrainStep.prepare with pinned packed
     uploads, device-cached labels, graph replay) train the model exactly like the same batches stepped inline."""
