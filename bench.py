@@ -33,6 +33,7 @@ PEAK_MFMA_F16 = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 M
 PEAK_HBM = 8000.0         # GB/s
 SETTLE = 30               # extra untimed steps after --warmup (see bench_training)
 LAST_LOSS = {}            # batch size -> total loss of the last timed step
+EXCHANGE = {}             # batch size -> how the user-table gradient was exchanged (data-parallel runs)
 
 C2 = dict(n_users=100_000, n_items=50_000, nnz=5_000_000, feat_dim=768, emb_dim=128, n_neg=10)
 
@@ -126,6 +127,9 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
         S.ops.KernelTimer.reset(False)
     loader.close()
     if trainer.fused is not None:
+        sp = trainer.fused._sparse
+        EXCHANGE[batch] = (f'all-gather of (row, gradient) pairs, capacity {sp[2]} rows per rank' if sp
+                           else 'dense all-reduce') if world > 1 or sp is not None else None
         trainer.fused.close()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -351,6 +355,8 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             out['config']['replica_param_checksum_spread'] = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
+            out['config']['param_checksum'] = [float(c) for c in chk]
+            out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
     roof = dominant_gemm(timings, args.steps) if rank == 0 else None
     if roof:
         out['roofline'] = roof

@@ -95,6 +95,12 @@ int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long 
 /* its dense gradient: dW[rows[j], :] += dOut[ii(j), :] (dW zero-initialised by the caller) */
 int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW, long ldw, long n, int D,
                          void* stream);
+/* the same dense gradient without float atomics, from row lists sorted by table row (new: the data-parallel exchange of
+ * lookup gradients, SURVEY.md 8(e) — every rank must produce the same bits). rows_sorted[j] = table row of sorted position j,
+ * perm[j] = its source row p: block p / blk (blocks are block_stride floats apart), row p % blk (rows ldo floats apart).
+ * Equal rows are added in sorted order by one thread; dW[row, :] += sum. */
+int sbr_scatter_add_rows_sorted(const float* dOut, long ldo, long blk, long block_stride, const long* perm,
+                                const int* rows_sorted, float* dW, long ldw, long n, int D, void* stream);
 
 /* nn.EmbeddingBag(mode='mean', padding_idx=pad) over padded tag lists — algorithms/sgd_alg.py:1336-1337, 1383-1386;
  * data/Feature.py:254-255. tags: [n_table_rows, T] int32. */

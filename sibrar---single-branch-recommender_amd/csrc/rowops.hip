@@ -219,6 +219,41 @@ extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_i
   return SBR_OK;
 }
 
+// The same gradient from row lists sorted by table row (data-parallel exchange of lookup gradients: every rank holds the same
+// gathered lists and must produce the same bits, so no float atomics): position j of the sorted order names source row
+// p = perm[j] — block p / blk at dOut + (p / blk) * block_stride, row p % blk of it. The thread of a segment head adds the
+// segment's rows in sorted (= stable source) order and owns the destination row.
+__global__ void scatter_add_rows_sorted_kernel(const float* __restrict__ dOut, long ldo, long blk, long block_stride,
+                                               const long* __restrict__ perm, const int* __restrict__ rows_sorted,
+                                               float* __restrict__ dW, long ldw, long n, int D) {
+  const long total = n * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long j = e / D;
+    const int c = (int)(e - j * D);
+    const int r = rows_sorted[j];
+    if (j > 0 && rows_sorted[j - 1] == r) continue;
+    float acc = 0.f;
+    for (long q = j; q < n && rows_sorted[q] == r; ++q) {
+      const long p = perm[q];
+      acc += dOut[(p / blk) * block_stride + (p % blk) * ldo + c];
+    }
+    dW[(long)r * ldw + c] += acc;
+  }
+}
+
+extern "C" int sbr_scatter_add_rows_sorted(const float* dOut, long ldo, long blk, long block_stride, const long* perm,
+                                           const int* rows_sorted, float* dW, long ldw, long n, int D, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(dOut && perm && rows_sorted && dW, "sbr_scatter_add_rows_sorted: null operand");
+  SBR_REQUIRE(blk >= 1, "sbr_scatter_add_rows_sorted: block length %ld", blk);
+  int blocks = sbr_cdiv(n * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  scatter_add_rows_sorted_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, ldo, blk, block_stride, perm, rows_sorted, dW,
+                                                                          ldw, n, D);
+  SBR_CHECK_LAUNCH("sbr_scatter_add_rows_sorted");
+  return SBR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // nn.EmbeddingBag(mode='mean', padding_idx=pad) over padded tag lists (sgd_alg.py:1336-1337; Feature.py:254-255)
 // one wave per output row; lanes run along D

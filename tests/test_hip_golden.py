@@ -327,12 +327,15 @@ def test_fused_step_graph_replay_equals_plain_launches(split, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_data_parallel_step_over_rccl_one_rank(monkeypatch, tmp_path):
+@pytest.mark.parametrize('exchange', ['sparse_user_rows', 'dense'])
+def test_data_parallel_step_over_rccl_one_rank(exchange, monkeypatch, tmp_path):
     """The data-parallel step with the real RCCL backend on the one GPU of the test box: a one-rank ``nccl`` process group and
     SBR_FORCE_DIST=1 make the engine run its multi-GPU launch structure (two graphs, asynchronous all-reduce of the user part
     on RCCL's stream between them, all-reduce of the rest, wait on the compute stream, division by the world size) and the
     item-sharded scoring its top-k all-gather + merge. Summing over one rank changes nothing, so losses, parameters and
-    top-k lists must equal the run without a process group. (More ranks need more GPUs: the driver's scaling run.)"""
+    top-k lists must equal the run without a process group. (More ranks need more GPUs: the driver's scaling run.)
+    ``sparse_user_rows``: the lookup user side all-gathers (table row, gradient row) pairs and scatters them after the
+    exchange instead of all-reducing the dense table gradient; one batch is ragged (unused capacity of the send buffer)."""
     import torch.distributed as dist
     import sibrar_amd as S
     ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
@@ -351,9 +354,10 @@ def test_data_parallel_step_over_rccl_one_rank(monkeypatch, tmp_path):
         rng = np.random.default_rng(9)
         losses = []
         for s_ in range(10):
-            u = torch.from_numpy(rng.integers(0, ds.n_users, size=64))
-            i = torch.from_numpy(rng.integers(0, ds.n_items, size=(64, 4)))
-            labels = torch.zeros(64, 4, dtype=torch.float64)
+            B = 64 if s_ != 5 else 40
+            u = torch.from_numpy(rng.integers(0, ds.n_users, size=B))
+            i = torch.from_numpy(rng.integers(0, ds.n_items, size=(B, 4)))
+            labels = torch.zeros(B, 4, dtype=torch.float64)
             labels[:, 0] = 1
             losses.append(torch.stack(fused.step(u, i, labels)).cpu())
         net.eval()
@@ -369,6 +373,7 @@ def test_data_parallel_step_over_rccl_one_rank(monkeypatch, tmp_path):
         return fused, losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
 
     monkeypatch.setenv('SBR_FORCE_SPLIT', '1')
+    monkeypatch.setenv('SBR_SPARSE_EXCHANGE', '1' if exchange == 'sparse_user_rows' else '0')
     plain = run()
     monkeypatch.setenv('SBR_FORCE_DIST', '1')
     dist.init_process_group('nccl', init_method=f'file://{tmp_path}/rdzv', rank=0, world_size=1, device_id=torch.device('cuda:0'))
@@ -378,6 +383,7 @@ def test_data_parallel_step_over_rccl_one_rank(monkeypatch, tmp_path):
     finally:
         dist.destroy_process_group()
     assert rccl[0].split and rccl[0].n_replays >= 4
+    assert bool(rccl[0]._sparse) == (exchange == 'sparse_user_rows') and not plain[0]._sparse
     for s_, (a, b) in enumerate(zip(plain[1], rccl[1])):
         close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
     skip = set(bn_shadowed_biases(plain[2].keys())) | {'item_embedding_module.sb_net.1.bias'}

@@ -424,3 +424,32 @@ def test_topk_long_rows_sampled_path_is_exact(I):
         assert all(len(set(r.tolist())) == k for r in srt)
         same = val[:, 1:].cpu() == val[:, :-1].cpu()
         assert (srt[:, 1:][same] > srt[:, :-1][same]).all()
+
+
+@pytest.mark.parametrize('W,cap,D,n_table', [(1, 5, 3, 4), (3, 40, 16, 25), (8, 1000, 128, 3000)])
+def test_scatter_add_rows_sorted_is_the_dense_gradient_without_atomics(W, cap, D, n_table):
+    """sbr_scatter_add_rows_sorted (data-parallel exchange of lookup gradients): W gathered blocks of ``cap`` (row, gradient)
+    pairs laid out like the all-gather's receive buffer [W][cap*D floats | cap int32], stable-sorted by table row ->
+    dW[row] += sum of the rows, equal to index_add in float64; a second run gives the same bits (fixed summation order);
+    and equal to the atomic scatter up to rounding."""
+    from importlib import import_module
+    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    g = torch.Generator().manual_seed(W * 1000 + cap)
+    grads = torch.randn(W, cap, D, generator=g)
+    rows = torch.randint(0, n_table, (W, cap), generator=g, dtype=torch.int32)
+    recv = torch.zeros(W, cap * (D + 1), dtype=torch.float32)
+    recv[:, :cap * D] = grads.reshape(W, -1)
+    recv[:, cap * D:] = rows.view(torch.float32)
+    recv = recv.to(DEV)
+    outs = []
+    for _ in range(2):
+        dW = torch.full((n_table, D), 0.5, device=DEV)
+        r_all = recv[:, cap * D:].view(torch.int32).reshape(-1)
+        rs, perm = torch.sort(r_all, stable=True)
+        _lib.call('sbr_scatter_add_rows_sorted', recv.data_ptr(), D, cap, recv.stride(0), perm.data_ptr(), rs.data_ptr(),
+                  dW.data_ptr(), dW.stride(0), W * cap, D, _lib.stream())
+        outs.append(dW.cpu())
+    ref = torch.full((n_table, D), 0.5, dtype=torch.float64)
+    ref.index_add_(0, rows.reshape(-1).long(), grads.reshape(-1, D).double())
+    close(outs[0], ref, rtol=1e-5, atol=1e-5, what='sorted scatter')
+    assert torch.equal(outs[0], outs[1])
