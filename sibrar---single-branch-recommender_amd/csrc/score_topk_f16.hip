@@ -386,304 +386,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   }
 }
 
-// =====================================================================================================================
-// v2 (D <= 128): 64 users per consumer wave, sorted top-k lists, direct insertion.
-//
-// Why: in the kernel above a wave owns 32 users, so every MFMA (32 cycles) needs a fresh 1 KiB B fragment from LDS — four
-// SIMDs ask for 128 B / cycle, the whole LDS bandwidth of the CU, and the MFMA-only ablation stops at 37 % of the fp16 peak;
-// the candidate buffers + compactions then cost another 35 % of the run time (4.4 k cycles per compaction behind that LDS
-// queue). Here a wave keeps TWO 32-user A fragment sets in registers and feeds each B fragment to two MFMAs (half the LDS
-// traffic per flop), and a workgroup covers 448 users (100 k users = 224 workgroups = ONE round on 256 CUs instead of 1.75).
-// 448 candidate buffers would not fit in LDS, so each row keeps only its sorted top-k list (k x 8 B): a candidate that beats
-// the row's k-th score is inserted by the owning wave in one LDS read / write round (lane l holds list entry l, entries
-// behind the insert position move down by one) and the k-th entry after the insert is the new threshold. No buffers, no
-// compaction, no fill counts; the number of inserts per row (~k ln(I / k)) is what it was.
-// Exclusions: every lane walks the sorted exclusion CSR row of one of the wave's 64 users (two bit words per lane, one per
-// 32-user tile). Everything else (loader wave, LDS-DMA ring with FULL / FREE counters, XOR swizzle, ordering rule score desc
-// then item index asc) is the scheme described at the top of this file.
-// =====================================================================================================================
-#define S2_WAVES 7
-#define S2_ROWS (S2_WAVES * 64)
-#define S2_THREADS ((S2_WAVES + 1) * 64)
-
-template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots; DBG: 1 = MFMA loop only, 2 = + threshold compares
-__global__ __launch_bounds__(S2_THREADS, 2) void score_topk_f16_v2_kernel(
-    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
-    const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k,
-    float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ dbgbuf) {
-  constexpr int D = KS * 16;
-  constexpr int ST_TILE = 64;
-  constexpr int NJ = 2;
-  constexpr int ROWB = D * 2;
-  constexpr int TILEB = ST_TILE * ROWB;
-  constexpr int CPR = D / 8;
-  constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);
-  constexpr int PER_T = (ST_TILE * CPR) / 64;
-  constexpr int LFL = NS > 2 ? NS - 2 : 1;
-  static_assert(LFL * PER_T <= 63, "vmcnt field");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  lds_u64* lst = (lds_u64*)(smem + NS * TILEB);                                                     // [S2_ROWS][k] sorted desc
-  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB + (size_t)S2_ROWS * k * 8);  // [S2_WAVES*64][2]
-  int* enx = reinterpret_cast<int*>(exw + S2_WAVES * 64 * 2);                                        // [S2_WAVES*64]
-  lds_int* full_lds = (lds_int*)(enx + S2_WAVES * 64);
-  lds_int* free_lds = full_lds + NS;
-  lds_int* enx_lds = (lds_int*)enx;
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const long row0 = (long)blockIdx.x * S2_ROWS;
-  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
-
-  if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
-  __syncthreads();                                         // the only workgroup barrier of the kernel
-
-  if (wave == S2_WAVES) {
-    // ---------------------------------------------- loader wave ------------------------------------------------------
-    for (int tile = 0; tile < n_tiles; ++tile) {
-      const int slot = tile % NS;
-      if (tile >= NS) {
-        const int need = S2_WAVES * (tile / NS);
-        while (st_peek(free_lds + slot) < need) __builtin_amdgcn_s_sleep(1);
-      }
-      const int j0 = tile * ST_TILE;
-      unsigned char* dst = smem + slot * TILEB;
-#pragma unroll
-      for (int q = 0; q < PER_T; ++q) {
-        const int P = q * 64 + lane;
-        const int i = P / CPR, cp = P % CPR;
-        int gi = j0 + i;
-        gi = gi < I ? gi : I - 1;
-        const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-      }
-      if (tile >= LFL) {
-        st_wait_vmcnt<LFL * PER_T>();
-        st_wave_fence();
-        *(volatile lds_int*)(full_lds + (tile - LFL) % NS) = tile - LFL + 1;
-      }
-    }
-    st_wait_vmcnt<0>();
-    st_wave_fence();
-    for (int tile = (n_tiles > LFL ? n_tiles - LFL : 0); tile < n_tiles; ++tile)
-      *(volatile lds_int*)(full_lds + tile % NS) = tile + 1;
-    return;
-  }
-
-  // ------------------------------------------------ consumer waves ------------------------------------------------------
-  // A fragments of the wave's two 32-user tiles: user row 64 * wave + 32 * mt + l31, k = 16 s + 8 half + j
-  f16x8 afrag[2][KS];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const long r = row0 + wave * 64 + mt * 32 + l31;
-    const long ur = r < Bu ? r : Bu - 1;
-    const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) afrag[mt][s] = src[2 * s + half];
-  }
-  // the wave's 64 top-k lists start empty (composite 0 sorts below every real entry)
-  lds_u64* wl = lst + (long)wave * 64 * k;
-  for (int e = lane; e < 64 * k; e += 64) wl[e] = 0ull;
-  exw[2 * t] = 0u;
-  exw[2 * t + 1] = 0u;
-  // exclusion cursor: lane L walks the sorted CSR row of user 64 * wave + L in step with the item tiles (see the kernel above)
-  const long my_row = row0 + wave * 64 + lane;
-  long eidx = 0, eend = 0;
-  int e0 = 0x7FFFFFFF;
-  {
-    int e1 = 0x7FFFFFFF;
-    if (my_row < Bu && excl_indptr) {
-      const long u = u_idx ? u_idx[my_row] : my_row;
-      long lo = excl_indptr[u];
-      eend = excl_indptr[u + 1];
-      long hi = eend;
-      while (lo < hi) {
-        const long mid = (lo + hi) >> 1;
-        if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
-      }
-      if (lo < eend) e0 = excl_indices[lo];
-      if (lo + 1 < eend) e1 = excl_indices[lo + 1];
-      eidx = lo + 1;
-    }
-    enx[t] = e1;
-  }
-  st_wave_fence();
-  bool e_pending = false;
-  // thresholds of the rows whose accumulators this lane holds: tile mt, register r <-> row 32 mt + (r & 3) + 8 (r >> 2) + 4 half
-  float thr[2][16];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) thr[mt][r] = -INFINITY;
-  }
-
-  unsigned long long t_wait = 0, t_evt = 0, n_evt = 0, n_ins = 0, n_cand = 0;
-  const unsigned long long t_begin = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-  for (int tl = 0; tl < n_tiles; ++tl) {
-    const int slot = tl % NS;
-    const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-    while (st_peek(full_lds + slot) != tl + 1) __builtin_amdgcn_s_sleep(1);
-    st_wave_fence();
-    if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
-    const unsigned char* cur = smem + slot * TILEB;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nj][r] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-        const int i = nj * 32 + l31;
-        const int c = 2 * s + half;
-        const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));
-        acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[0][s], b, acc[0][nj], 0, 0, 0);
-        acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[1][s], b, acc[1][nj], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]) : "memory");
-    if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);
-
-    // exclusions of this tile: one bit per excluded (row, column) for the lane that holds that accumulator — lane
-    // (col & 31) + 32 ((row >> 2) & 1), word mt = row >> 5, bit (col >> 5) * 16 + (row & 3) + 4 ((row & 31) >> 3)
-    const int j0 = tl * ST_TILE;
-    const int gbase = item_offset + j0;
-    bool wrote_ex = false;
-    for (int round = 0;; ++round) {
-      const bool take = e0 < gbase + ST_TILE;
-      if (!__ballot(take)) break;
-      if (e_pending) st_wait_vmcnt<0>();
-      e_pending = false;
-      wrote_ex = true;
-      if (take) {
-        const int col = e0 - gbase;
-        const int tgt = wave * 64 + (col & 31) + 32 * ((l31 >> 2) & 1);
-        atomicOr(&exw[2 * tgt + half], 1u << ((col >> 5) * 16 + (l31 & 3) + 4 * (l31 >> 3)));
-        st_wave_fence();
-        e0 = enx_lds[t];
-        ++eidx;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (eidx < eend) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(excl_indices + eidx),
-                                           (__attribute__((address_space(3))) void*)(enx + wave * 64), 4, 0, 0);
-        } else {
-          enx_lds[t] = 0x7FFFFFFF;
-          st_wave_fence();
-        }
-      }
-      e_pending = true;
-    }
-    if constexpr (DBG == 1) {
-      asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
-      continue;
-    }
-    const bool have_ex = __ballot(wrote_ex) != 0ull;
-    unsigned int ex[2] = {0u, 0u};
-    bool ex_loaded = false;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-        unsigned long long br[16];
-        unsigned long long any = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { br[r] = __ballot(acc[mt][nj][r] > thr[mt][r]); any |= br[r]; }
-        if constexpr (DBG == 2) { if (any) asm volatile("s_nop 0"); continue; }
-        if (!any) continue;
-        if (have_ex && !ex_loaded) { st_wave_fence(); ex[0] = exw[2 * t]; ex[1] = exw[2 * t + 1]; ex_loaded = true; }
-        const bool in_range = j0 + nj * 32 + l31 < I;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float thr_r = thr[mt][r];
-          if (br[r]) {                                                   // SGPR test: no VALU work on the common path
-            const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-            const float v = acc[mt][nj][r];
-            const bool cand = in_range && (v > thr_r) && !((ex[mt] >> (nj * 16 + r)) & 1u);
-            unsigned long long bal = __ballot(cand);
-            while (bal) {                                                // wave-uniform; candidates in item order
-              const int src = __ffsll((long long)bal) - 1;
-              bal &= bal - 1ull;
-              if constexpr (DBG == 4) ++n_cand;
-              const float sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src));
-              const int sh = src >> 5;
-              const int lrow = wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * sh;
-              const unsigned int item = (unsigned int)(item_offset + j0 + nj * 32 + (src & 31));
-              const unsigned long long keyc = ((unsigned long long)st_f2key(sv) << 32) | (unsigned long long)(0xFFFFFFFFu - item);
-              lds_u64* L = lst + lrow * k;
-              st_wave_fence();
-              const bool in_list = lane < k;
-              const unsigned long long old = in_list ? L[lane] : 0ull;
-              const unsigned long long prev = (in_list && lane > 0) ? L[lane - 1] : ~0ull;
-              const int pos = __popcll(__ballot(in_list && old > keyc));  // entries that stay in front of the candidate
-              if (pos < k) {
-                if constexpr (DBG == 4) ++n_ins;
-                const unsigned long long nv = lane == pos ? keyc : prev;  // new content of list position `lane` (>= pos)
-                st_wave_fence();
-                if (in_list && lane >= pos) L[lane] = nv;
-                st_wave_fence();
-                const unsigned int kth = (unsigned int)__builtin_amdgcn_readlane((int)(nv >> 32), k - 1);
-                const float nthr = kth ? st_key2f(kth) : -INFINITY;      // key 0 = the list is not full yet
-                if (half == sh) thr_r = nthr;
-              }
-            }
-            if constexpr (DBG == 4) { t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
-          }
-          thr[mt][r] = thr_r;
-        }
-      }
-    }
-    if (have_ex) { exw[2 * t] = 0u; exw[2 * t + 1] = 0u; st_wave_fence(); }
-  }
-
-  if constexpr (DBG == 4) {
-    if (lane == 0 && dbgbuf) {
-      unsigned long long* d = dbgbuf + ((long)blockIdx.x * S2_WAVES + wave) * 8;
-      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_evt; d[3] = n_cand; d[4] = n_evt; d[5] = n_ins;
-    }
-  }
-  // output: the wave's 64 sorted lists, coalesced over (row, position)
-  st_wave_fence();
-  for (int e = lane; e < 64 * k; e += 64) {
-    const int r = e / k;
-    const long ur = row0 + wave * 64 + r;
-    if (ur >= Bu) continue;
-    const unsigned long long c = wl[e];
-    float val = -INFINITY;
-    int idx = -1;
-    if (c) {
-      val = st_key2f((unsigned int)(c >> 32));
-      idx = (int)(0xFFFFFFFFu - (unsigned int)(c & 0xFFFFFFFFull));
-    }
-    out_val[ur * k + (e - r * k)] = val;
-    out_idx[ur * k + (e - r * k)] = idx;
-  }
-}
-
-template <int KS, int NS>
-static int s2_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
-                     int item_offset, int k, float* out_val, int* out_idx, void* dbg_buf, hipStream_t s) {
-  const size_t lds = (size_t)NS * 64 * KS * 32 + (size_t)S2_ROWS * k * 8 + S2_WAVES * 64 * 12 + 2 * NS * 4 + 16;
-  SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations (see above)
-  auto kern = dbg == 1 ? score_topk_f16_v2_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_v2_kernel<KS, NS, 2> :
-              (dbg == 4 ? score_topk_f16_v2_kernel<KS, NS, 4> : score_topk_f16_v2_kernel<KS, NS, 0>));
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
-    return SBR_ERR_HIP;
-  }
-  kern<<<sbr_cdiv(Bu, S2_ROWS), S2_THREADS, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx,
-                                                      item_offset, k, out_val, out_idx, (unsigned long long*)dbg_buf);
-  SBR_CHECK_LAUNCH("sbr_score_topk_f16");
-  return SBR_OK;
-}
-
 static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64) c = 64; return c; }
 
 extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
@@ -719,18 +421,6 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE(U_f16 && I_f16 && out_val && out_idx, "sbr_score_topk_f16: null operand");
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
-  // D <= 128: the 64-users-per-wave kernel (ring depth by what the k-entry lists leave of the LDS); SBR_SCORER_V1=1 keeps the
-  // first kernel for A/B timing. D = 256 stays on the first kernel (two A fragment sets would need 128 VGPRs).
-  const bool v1 = getenv("SBR_SCORER_V1") && atoi(getenv("SBR_SCORER_V1")) != 0;
-  if (!v1 && D == 128) {
-    if (k <= 20) return s2_launch<8, 5>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    if (k <= 27) return s2_launch<8, 3>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    return s2_launch<8, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-  }
-  if (!v1 && D == 64) {
-    if (k <= 24) return s2_launch<4, 6>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-    return s2_launch<4, 4>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
-  }
   switch (D) {
     case 64: return st_launch<4, 6, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     case 128: return st_launch<8, 5, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
