@@ -217,6 +217,8 @@ int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const lon
 int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
                        const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val, int* out_idx,
                        void* workspace, long workspace_bytes, void* stream);
+/* bytes of `workspace` for the call above: per-user candidate buffers of the 64-users-per-wave kernel (D = 64 | 128; L2-resident
+ * scratch touched only by the wave that owns the user; contents need no initialisation). */
 long sbr_score_topk_f16_workspace(long Bu, int I, int k);
 /* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
 int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);

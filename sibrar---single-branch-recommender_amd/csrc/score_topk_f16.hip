@@ -386,9 +386,438 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
   }
 }
 
+// =====================================================================================================================
+// Wide kernel (D <= 128): 64 users per consumer wave, candidate buffers in global memory.
+//
+// In the kernel above a wave owns 32 users, so every MFMA (32 cycles) needs a fresh 1 KiB B fragment from LDS — four SIMDs
+// ask for 128 B / cycle, the whole LDS bandwidth of the CU (MFMA-only ablation: 37 % of the fp16 peak) — and 100k users are
+// 1.75 rounds of 224-user workgroups. Here a wave keeps TWO 32-user A fragment sets in registers and feeds each B fragment
+// to two MFMAs (half the LDS traffic per flop), and a workgroup covers 448 users (100k users = 224 workgroups = one round).
+// 448 candidate buffers do not fit in LDS, so they live in a global workspace (S3_CAP entries of 8 B per user, touched only
+// by the owning wave, L2-resident). Hot path per accumulator register: v_cmp against the row's threshold; survivors are
+// appended with fire-and-forget global stores at ballot-derived positions. There is no overflow handling on the hot path:
+// before the MFMAs of a tile every row is guaranteed 64 free entries (one tile can add at most 64 candidates to a row).
+// That guarantee is kept by a cold maintenance step at the top of the tile loop (taken when a lane's high-water mark says
+// some row is above S3_CAP - 64): the owning wave compacts those rows — 64 lanes load the <= 128 entries, rank them by
+// counting over v_readlane broadcasts (no LDS traffic), store the k best back sorted — and raises their thresholds.
+// Every lane walks the exclusion CSR row of one of the wave's 64 users (two bit words per lane). Loader wave, LDS-DMA ring,
+// XOR swizzle and the ordering rule (score desc, item index asc) are those described at the top of this file.
+// =====================================================================================================================
+#define S3_WAVES 7
+#define S3_ROWS (S3_WAVES * 64)
+#define S3_THREADS ((S3_WAVES + 1) * 64)
+#define S3_CAP 128                       // candidate buffer entries per user (global workspace)
+#define S3_LIMIT (S3_CAP - 64)           // fill above which a row is compacted before the next tile
+
+// All 64 lanes of the owning wave: keep the k best of the first n (<= 128, wave-uniform) entries of the global row buffer b
+// (lane l holds entries l and l + 64) at b[0..min(n, k)), UNSORTED, and return the new threshold (-inf while fewer than k
+// entries exist). Selection, not sorting: the k-th largest score key is found by a bitwise binary search over ballot counts
+// (32 steps of v_cmp + s_bcnt1, ~600 cycles; a full ranking by counting costs ~10 k), ties at that key are resolved on the item
+// half of the composite the same way (rare). e / keep: the lane's two entries and whether they survived.
+__device__ __forceinline__ float s3_select(unsigned long long* b, int n_any, int k, int lane, unsigned long long e[2],
+                                           bool keep[2]) {
+  const int n = __builtin_amdgcn_readfirstlane(n_any);
+  // The buffer is written and read by this wave only: its stores and loads pass through the same CU's vector memory path in
+  // order, so a workgroup-scope fence (compiler ordering + store drain; no L2 write-back — an agent-scope release costs
+  // ~18 us here because the XCDs' L2s are not coherent with each other) is all the synchronisation the reload needs.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  e[0] = lane < n ? b[lane] : 0ull;
+  e[1] = lane + 64 < n ? b[lane + 64] : 0ull;
+  keep[0] = lane < n;
+  keep[1] = lane + 64 < n;
+  if (n < k) return -INFINITY;                              // nothing to drop: entries stay where they are
+  const unsigned int h0 = (unsigned int)(e[0] >> 32), h1 = (unsigned int)(e[1] >> 32);
+  unsigned int T = 0u;                                       // k-th largest score key (real keys are > 0, empties are 0)
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    const int cnt = __popcll(__ballot(h0 >= trial)) + __popcll(__ballot(h1 >= trial));
+    T = cnt >= k ? trial : T;
+  }
+  unsigned long long C = (unsigned long long)T << 32;
+  const int c_ge = __popcll(__ballot(h0 >= T)) + __popcll(__ballot(h1 >= T));
+  if (c_ge != k) {
+    // several entries share the k-th key: of those, the ones with the largest low words (= smallest item indices) stay
+    const int need = k - (__popcll(__ballot(h0 > T)) + __popcll(__ballot(h1 > T)));
+    const unsigned int l0 = (unsigned int)e[0], l1 = (unsigned int)e[1];
+    unsigned int Lw = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = Lw | (1u << bit);
+      const int cnt = __popcll(__ballot(h0 == T && l0 >= trial)) + __popcll(__ballot(h1 == T && l1 >= trial));
+      Lw = cnt >= need ? trial : Lw;
+    }
+    C |= (unsigned long long)Lw;
+  }
+  keep[0] = e[0] >= C;
+  keep[1] = e[1] >= C;
+  const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
+  const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b0, 0u));
+  const int p1 = __popcll(b0) + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b1, 0u));
+  if (keep[0]) b[p0] = e[0];
+  if (keep[1]) b[p1] = e[1];
+  return st_key2f(T);
+}
+
+template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots; DBG: 1 = MFMA loop only, 2 = + threshold compares
+__global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
+    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
+    const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k,
+    float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ gbuf,
+    unsigned long long* __restrict__ dbgbuf) {
+  constexpr int D = KS * 16;
+  constexpr int ST_TILE = 64;
+  constexpr int NJ = 2;
+  constexpr int ROWB = D * 2;
+  constexpr int TILEB = ST_TILE * ROWB;
+  constexpr int CPR = D / 8;
+  constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);
+  constexpr int PER_T = (ST_TILE * CPR) / 64;
+  constexpr int LFL0 = NS > 2 ? NS - 2 : 1;
+  // tiles in flight behind the awaited one: the vmcnt field has 6 bits (D = 128: 3 tiles of 16 DMA instructions; measured with
+  // 2 instead of 3: the MFMA-only ablation does not move, 1.27 vs 1.34 ms — the loader's depth is not what bounds the main loop)
+  constexpr int LFL = LFL0 * PER_T <= 63 ? LFL0 : 63 / PER_T;
+  static_assert(LFL >= 1 && LFL * PER_T <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB);                            // [S3_WAVES*64][2]
+  int* enx = reinterpret_cast<int*>(exw + S3_WAVES * 64 * 2);                                        // [S3_WAVES*64]
+  int* tab_fill = enx + S3_WAVES * 64;                   // [S3_WAVES*64] maintenance step: fill count / new threshold per row
+  float* tab_thr = reinterpret_cast<float*>(tab_fill + S3_WAVES * 64);
+  lds_int* full_lds = (lds_int*)(tab_thr + S3_WAVES * 64);
+  lds_int* free_lds = full_lds + NS;
+  lds_int* enx_lds = (lds_int*)enx;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const long row0 = (long)blockIdx.x * S3_ROWS;
+  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
+
+  if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
+  __syncthreads();                                         // the only workgroup barrier of the kernel
+
+  if (wave == S3_WAVES) {
+    // ---------------------------------------------- loader wave ------------------------------------------------------
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int slot = tile % NS;
+      if (tile >= NS) {
+        const int need = S3_WAVES * (tile / NS);
+        while (st_peek(free_lds + slot) < need) __builtin_amdgcn_s_sleep(1);
+      }
+      const int j0 = tile * ST_TILE;
+      unsigned char* dst = smem + slot * TILEB;
+#pragma unroll
+      for (int q = 0; q < PER_T; ++q) {
+        const int P = q * 64 + lane;
+        const int i = P / CPR, cp = P % CPR;
+        int gi = j0 + i;
+        gi = gi < I ? gi : I - 1;
+        const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+      }
+      if (tile >= LFL) {
+        st_wait_vmcnt<LFL * PER_T>();
+        st_wave_fence();
+        *(volatile lds_int*)(full_lds + (tile - LFL) % NS) = tile - LFL + 1;
+      }
+    }
+    st_wait_vmcnt<0>();
+    st_wave_fence();
+    for (int tile = (n_tiles > LFL ? n_tiles - LFL : 0); tile < n_tiles; ++tile)
+      *(volatile lds_int*)(full_lds + tile % NS) = tile + 1;
+    return;
+  }
+
+  // ------------------------------------------------ consumer waves ------------------------------------------------------
+  // A fragments of the wave's two 32-user tiles: user row 64 * wave + 32 * mt + l31, k = 16 s + 8 half + j
+  f16x8 afrag[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long r = row0 + wave * 64 + mt * 32 + l31;
+    const long ur = r < Bu ? r : Bu - 1;
+    const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) afrag[mt][s] = src[2 * s + half];
+  }
+  unsigned long long* gb = gbuf + row0 * S3_CAP;         // candidate buffers of this workgroup's rows
+  exw[2 * t] = 0u;
+  exw[2 * t + 1] = 0u;
+  // exclusion cursor: lane L walks the sorted CSR row of user 64 * wave + L in step with the item tiles (see the kernel above)
+  const long my_row = row0 + wave * 64 + lane;
+  long eidx = 0, eend = 0;
+  int e0 = 0x7FFFFFFF;
+  {
+    int e1 = 0x7FFFFFFF;
+    if (my_row < Bu && excl_indptr) {
+      const long u = u_idx ? u_idx[my_row] : my_row;
+      long lo = excl_indptr[u];
+      eend = excl_indptr[u + 1];
+      long hi = eend;
+      while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
+      }
+      if (lo < eend) e0 = excl_indices[lo];
+      if (lo + 1 < eend) e1 = excl_indices[lo + 1];
+      eidx = lo + 1;
+    }
+    enx[t] = e1;
+  }
+  st_wave_fence();
+  bool e_pending = false;
+  // thresholds of the rows whose accumulators this lane holds: tile mt, register r <-> row 32 mt + (r & 3) + 8 (r >> 2) + 4 half
+  float thr[2][16];
+  unsigned int fillp[2][4];             // fill counts of the same rows, 8 bits each (<= S3_CAP + 63 < 256): register r in byte r & 3 of word r >> 2
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) thr[mt][r] = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fillp[mt][q] = 0u;
+  }
+  int hw = 0;                           // the largest fill count among this lane's rows
+  int* wfill = tab_fill + wave * 64;
+  float* wthr = tab_thr + wave * 64;
+  unsigned long long* wgb = gb + (long)wave * 64 * S3_CAP;            // wave-uniform
+  const unsigned int hoff = (unsigned int)half * (4u * S3_CAP * 8u);
+
+  unsigned long long t_wait = 0, t_evt = 0, n_evt = 0, n_ins = 0, n_cand = 0, t_cmp = 0;
+  const unsigned long long t_begin = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int tl = 0; tl < n_tiles; ++tl) {
+    const int slot = tl % NS;
+    if (__ballot(hw > S3_LIMIT)) {
+      // ---- maintenance (cold): compact the rows above S3_LIMIT so that this tile's appends cannot overflow
+      const unsigned long long tm0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wfill[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = (int)((fillp[mt][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+      }
+      st_wave_fence();
+      const int myfill = wfill[lane];
+      unsigned long long need = __ballot(myfill > S3_LIMIT);
+      const unsigned long long done = need;
+      while (need) {
+        const int row = __ffsll((long long)need) - 1;
+        need &= need - 1ull;
+        const int n = __builtin_amdgcn_readlane(myfill, row);
+        unsigned long long e[2];
+        bool kp[2];
+        const float nt = s3_select(wgb + (long)row * S3_CAP, n, k, lane, e, kp);
+        if (lane == 0) { wthr[row] = nt; wfill[row] = n < k ? n : k; }
+        if constexpr (DBG == 4) ++n_ins;
+      }
+      st_wave_fence();
+      hw = 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fillp[mt][q] = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const bool d = (done >> row) & 1ull;
+          const float nt = wthr[row];
+          const int nf = wfill[row];                                   // unchanged rows read back what was written above
+          thr[mt][r] = d ? nt : thr[mt][r];
+          fillp[mt][r >> 2] |= (unsigned int)nf << (8 * (r & 3));
+          hw = nf > hw ? nf : hw;
+        }
+      }
+      if constexpr (DBG == 4) t_wait += 0 * tm0, t_cmp += __builtin_amdgcn_s_memtime() - tm0;
+    }
+    const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+    while (st_peek(full_lds + slot) != tl + 1) __builtin_amdgcn_s_sleep(1);
+    st_wave_fence();
+    if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
+    const unsigned char* cur = smem + slot * TILEB;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nj][r] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        const int i = nj * 32 + l31;
+        const int c = 2 * s + half;
+        const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));
+        acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[0][s], b, acc[0][nj], 0, 0, 0);
+        acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[1][s], b, acc[1][nj], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]) : "memory");
+    if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);
+
+    // exclusions of this tile: one bit per excluded (row, column) for the lane that holds that accumulator — lane
+    // (col & 31) + 32 ((row >> 2) & 1), word mt = row >> 5, bit (col >> 5) * 16 + (row & 3) + 4 ((row & 31) >> 3)
+    const int j0 = tl * ST_TILE;
+    const int gbase = item_offset + j0;
+    bool wrote_ex = false;
+    for (int round = 0;; ++round) {
+      const bool take = e0 < gbase + ST_TILE;
+      if (!__ballot(take)) break;
+      if (e_pending) st_wait_vmcnt<0>();
+      e_pending = false;
+      wrote_ex = true;
+      if (take) {
+        const int col = e0 - gbase;
+        const int tgt = wave * 64 + (col & 31) + 32 * ((l31 >> 2) & 1);
+        atomicOr(&exw[2 * tgt + half], 1u << ((col >> 5) * 16 + (l31 & 3) + 4 * (l31 >> 3)));
+        st_wave_fence();
+        e0 = enx_lds[t];
+        ++eidx;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (eidx < eend) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(excl_indices + eidx),
+                                           (__attribute__((address_space(3))) void*)(enx + wave * 64), 4, 0, 0);
+        } else {
+          enx_lds[t] = 0x7FFFFFFF;
+          st_wave_fence();
+        }
+      }
+      e_pending = true;
+    }
+    if constexpr (DBG == 1) {
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+      continue;
+    }
+    const bool have_ex = __ballot(wrote_ex) != 0ull;
+    unsigned int ex[2] = {0u, 0u};
+    bool ex_loaded = false;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        unsigned long long br[16];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { br[r] = __ballot(acc[mt][nj][r] > thr[mt][r]); any |= br[r]; }
+        if constexpr (DBG == 2) { if (any) asm volatile("s_nop 0"); continue; }
+        if (!any) continue;
+        if (have_ex && !ex_loaded) { st_wave_fence(); ex[0] = exw[2 * t]; ex[1] = exw[2 * t + 1]; ex_loaded = true; }
+        const bool in_range = j0 + nj * 32 + l31 < I;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float thr_r = thr[mt][r];
+          if (br[r]) {                                                   // SGPR test: no VALU work on the common path
+            const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+            const float v = acc[mt][nj][r];
+            const bool cand = in_range && (v > thr_r) && !((ex[mt] >> (nj * 16 + r)) & 1u);
+            const unsigned long long bal = __ballot(cand);
+            const unsigned int bal_lo = (unsigned int)bal, bal_hi = (unsigned int)(bal >> 32);
+            const int n_lo = __popc(bal_lo), n_hi = __popc(bal_hi);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi(bal_hi, __builtin_amdgcn_mbcnt_lo(bal_lo, 0u));
+            int fill_r = (int)((fillp[mt][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+            const int pos = fill_r + (half ? below - n_lo : below);      // < S3_CAP: the row had 64 free entries at tile start
+            const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) |
+                                           (unsigned long long)(0xFFFFFFFFu - (unsigned)(item_offset + j0 + nj * 32 + l31));
+            // row mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half: uniform base + 32-bit lane offset (no per-row 64-bit pointers)
+            const unsigned int off = hoff + ((unsigned int)pos << 3) + (unsigned int)((mt * 32 + (r & 3) + 8 * (r >> 2)) * S3_CAP * 8);
+            if (cand) *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(wgb) + off) = key;
+            const int add = half ? n_hi : n_lo;
+            fill_r += add;
+            fillp[mt][r >> 2] += (unsigned int)add << (8 * (r & 3));
+            hw = fill_r > hw ? fill_r : hw;
+            if constexpr (DBG == 4) { n_cand += __popcll(bal); t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
+          }
+        }
+      }
+    }
+    if (have_ex) { exw[2 * t] = 0u; exw[2 * t + 1] = 0u; st_wave_fence(); }
+  }
+
+  if constexpr (DBG == 4) {
+    if (lane == 0 && dbgbuf) {
+      unsigned long long* d = dbgbuf + ((long)blockIdx.x * S3_WAVES + wave) * 8;
+      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_evt; d[3] = n_cand; d[4] = n_evt; d[5] = n_ins; d[6] = t_cmp;
+    }
+  }
+  // final compaction + output of the wave's 64 rows: the lane that holds the entry of rank j writes output position j
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      wfill[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = (int)((fillp[mt][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+  }
+  st_wave_fence();
+  const int myfill = wfill[lane];
+  for (int row = 0; row < 64; ++row) {
+    const long ur = row0 + wave * 64 + row;
+    if (ur >= Bu) break;
+    const int n = __builtin_amdgcn_readlane(myfill, row);
+    unsigned long long e[2];
+    bool kp[2];
+    s3_select(wgb + (long)row * S3_CAP, n, k, lane, e, kp);
+    // rank the (at most k) survivors among themselves: broadcast each of them with v_readlane
+    int rk[2] = {0, 0};
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int h32 = (int)(e[part] >> 32), l32 = (int)e[part];
+      for (unsigned long long m = __ballot(kp[part]); m; m &= m - 1ull) {
+        const int j = __ffsll((long long)m) - 1;
+        const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(h32, j) << 32) |
+                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(l32, j);
+        rk[0] += kj > e[0];
+        rk[1] += kj > e[1];
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      if (kp[part]) {
+        out_val[ur * k + rk[part]] = st_key2f((unsigned int)(e[part] >> 32));
+        out_idx[ur * k + rk[part]] = (int)(0xFFFFFFFFu - (unsigned int)(e[part] & 0xFFFFFFFFull));
+      }
+    }
+    if (lane >= n && lane < k) {                             // fewer than k candidates: empty slots behind them
+      out_val[ur * k + lane] = -INFINITY;
+      out_idx[ur * k + lane] = -1;
+    }
+  }
+}
+
+template <int KS, int NS>
+static int s3_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+                     int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
+  const long rows_padded = sbr_cdiv(Bu, S3_ROWS) * (long)S3_ROWS;
+  const long need = rows_padded * S3_CAP * 8;
+  SBR_REQUIRE(workspace && workspace_bytes >= need + (getenv("SBR_ST_DEBUG") && atoi(getenv("SBR_ST_DEBUG")) == 4 ? sbr_cdiv(Bu, S3_ROWS) * S3_WAVES * 64L : 0L),
+              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", need, workspace_bytes);
+  void* dbg_buf = (char*)workspace + need;
+  const size_t lds = (size_t)NS * 64 * KS * 32 + S3_WAVES * 64 * 20 + 2 * NS * 4 + 16;
+  SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
+  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations (see above)
+  auto kern = dbg == 1 ? score_topk_f16_wide_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_wide_kernel<KS, NS, 2> :
+              (dbg == 4 ? score_topk_f16_wide_kernel<KS, NS, 4> : score_topk_f16_wide_kernel<KS, NS, 0>));
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
+    return SBR_ERR_HIP;
+  }
+  kern<<<sbr_cdiv(Bu, S3_ROWS), S3_THREADS, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx,
+                                                      item_offset, k, out_val, out_idx, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
+  SBR_CHECK_LAUNCH("sbr_score_topk_f16");
+  return SBR_OK;
+}
 static int st_cap(int k) { int c = 2 * k; if (c < k + 16) c = k + 16; if (c > 64) c = 64; return c; }
 
-extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) { (void)Bu; (void)I; (void)k; return 0; }
+static bool st_use_wide(int D) {
+  const bool v1 = getenv("SBR_SCORER_V1") && atoi(getenv("SBR_SCORER_V1")) != 0;
+  return !v1 && (D == 128 || D == 64);
+}
+
+// bytes of the candidate-buffer workspace (wide kernel: S3_CAP entries per user, users padded to whole workgroups; + the
+// cycle stamps of SBR_ST_DEBUG=4). D = 0: the largest over all D.
+extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) {
+  (void)I; (void)k;
+  const long wgs = sbr_cdiv(Bu, S3_ROWS);
+  return wgs * S3_ROWS * (long)S3_CAP * 8 + wgs * S3_WAVES * 64L;
+}
 
 template <int KS, int NS, int ST_TILE>
 static int st_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
@@ -414,13 +843,18 @@ static int st_launch(const void* U, const void* It, long Bu, int I, const long* 
 extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
                                   const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val,
                                   int* out_idx, void* workspace, long workspace_bytes, void* stream) {
-  (void)workspace_bytes;    // workspace: unused by the production kernel (SBR_ST_DEBUG=4 writes per-wave cycle stamps there)
   SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
   SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
   if (Bu == 0) return SBR_OK;
   SBR_REQUIRE(U_f16 && I_f16 && out_val && out_idx, "sbr_score_topk_f16: null operand");
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
+  // D <= 128: the 64-users-per-wave kernel (SBR_SCORER_V1=1 keeps the first kernel for A/B timing). D = 256 stays on the first
+  // kernel: two A fragment sets would need 128 VGPRs.
+  if (st_use_wide(D)) {
+    if (D == 128) return s3_launch<8, 6>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    return s3_launch<4, 8>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+  }
   switch (D) {
     case 64: return st_launch<4, 6, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
     case 128: return st_launch<8, 5, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);

@@ -232,7 +232,8 @@ def test_topk_exact_ties_and_mask():
     assert torch.isinf(out.cpu()[dense]).all() and torch.equal(out.cpu()[~dense], before.cpu()[~dense])
 
 
-@pytest.mark.parametrize('Bu,I,D,k', [(5, 70, 64, 3), (300, 1000, 128, 20), (257, 3299, 64, 10), (1000, 5000, 256, 20)])
+@pytest.mark.parametrize('Bu,I,D,k', [(5, 70, 64, 3), (300, 1000, 128, 20), (257, 3299, 64, 10), (1000, 5000, 256, 20),
+                                      (500, 2000, 128, 32), (449, 700, 128, 1), (1000, 20000, 128, 20)])
 def test_fused_f16_scorer_matches_unfused(Bu, I, D, k):
     """fp16-MFMA score + mask + top-k == (fp32 matmul of the same fp16-rounded inputs -> mask -> exact top-k)."""
     ops = S().ops
@@ -269,6 +270,38 @@ def test_fused_f16_scorer_sorted_catalogue_and_item_offset():
     close(val.cpu(), tv, rtol=1e-6, atol=1e-6, what='values')
     assert (idx.cpu() >= 1000).all()
     close(torch.gather(ref, 1, idx.cpu().long() - 1000), tv, rtol=1e-6, atol=1e-6, what='indices')
+
+
+@pytest.mark.parametrize('D', [64, 128, 256])
+def test_fused_f16_scorer_ties_and_short_catalogues(D):
+    """Exact ordering rule under massive ties (scores take ~20 distinct values, so the k-th score is shared by hundreds of
+    items: the selection step has to resolve the tie on the item index) and catalogues shorter than k (missing slots: -inf / -1);
+    exclusions on. Reference: stable sort by (score desc, item index asc)."""
+    ops = S().ops
+    import scipy.sparse as sp
+    g = torch.Generator().manual_seed(D)
+    Bu, I, k = 130, 3000, 20
+    u = torch.zeros(Bu, D)
+    it = torch.zeros(I, D)
+    u[:, :4] = torch.randint(-1, 2, (Bu, 4), generator=g).float()
+    it[:, :4] = torch.randint(-2, 3, (I, 4), generator=g).float()
+    m = sp.random(Bu, I, density=0.05, format='csr', random_state=5)
+    m.sort_indices()
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(DEV)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(DEV)
+    uidx = torch.arange(Bu, device=DEV)
+    val, idx = ops.score_topk_f16(u.half().to(DEV), it.half().to(DEV), k, uidx, indptr, indices)
+    ref = (u.double() @ it.double().t()).numpy()
+    ref[m.toarray() != 0] = -np.inf
+    order = np.lexsort((np.broadcast_to(np.arange(I), ref.shape), -ref), axis=1)[:, :k]
+    assert np.array_equal(idx.cpu().numpy(), order)
+    assert np.array_equal(val.cpu().numpy().astype(np.float64), np.take_along_axis(ref, order, axis=1))
+    # a 7-item catalogue: 7 sorted entries, then empty slots
+    val, idx = ops.score_topk_f16(u.half().to(DEV), it[:7].half().to(DEV), k)
+    ref7 = (u.double() @ it[:7].double().t()).numpy()
+    o7 = np.lexsort((np.broadcast_to(np.arange(7), ref7.shape), -ref7), axis=1)
+    assert np.array_equal(idx.cpu().numpy()[:, :7], o7) and (idx.cpu().numpy()[:, 7:] == -1).all()
+    assert np.isneginf(val.cpu().numpy()[:, 7:]).all()
 
 
 def test_rank_metrics_vs_oracle():

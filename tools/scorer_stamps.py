@@ -1,3 +1,6 @@
+"""Cycle stamps of the fused scorer (SBR_ST_DEBUG=4): per consumer wave total cycles, time waiting for tiles, time in candidate
+blocks, compaction time and counts. D = 64 | 128: the 64-users-per-wave kernel (448 users per workgroup); D = 256 or
+SBR_SCORER_V1=1: the 32-users-per-wave kernel (224 users per workgroup; fields: total, wait, events, overflow)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['SBR_ST_DEBUG'] = '4'
@@ -7,16 +10,26 @@ from importlib import import_module
 L = import_module('sibrar---single-branch-recommender_amd._lib')
 g = torch.Generator(device='cuda').manual_seed(1)
 Bu, I, D = 100000, 50000, int(sys.argv[1]) if len(sys.argv) > 1 else 128
+wide = D in (64, 128) and os.environ.get('SBR_SCORER_V1', '0') == '0'
 u = (torch.randn(Bu, D, device='cuda', generator=g) / 8).half()
 it = (torch.randn(I, D, device='cuda', generator=g) / 8).half()
-nwg = (Bu + 223) // 224
-dbg = torch.zeros(nwg * 7 * 8, dtype=torch.int64, device='cuda')
+rows = 448 if wide else 224
+nwg = (Bu + rows - 1) // rows
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, 20))
+ws = torch.zeros(max(need, nwg * 7 * 64), dtype=torch.uint8, device='cuda')
 val = torch.empty(Bu, 20, device='cuda'); idx = torch.empty(Bu, 20, dtype=torch.int32, device='cuda')
 for _ in range(2):
-    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 20, val.data_ptr(), idx.data_ptr(), dbg.data_ptr(), dbg.numel() * 8, L.stream())
+    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 20, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nwg * 7, 8).astype(np.float64)
-tot, wait, evt, ovf, nevt, novf = [d[:, i] for i in range(6)]
-print(f'per wave (mean over {len(d)} waves): total {tot.mean():.3g} cyc | barrier+dma wait {wait.mean():.3g} ({100*wait.mean()/tot.mean():.1f}%) | '
-      f'event blocks {evt.mean():.3g} ({100*evt.mean()/tot.mean():.1f}%), n={nevt.mean():.0f}, {evt.mean()/max(nevt.mean(),1):.0f} cyc/event | '
-      f'overflow {ovf.mean():.3g} ({100*ovf.mean()/tot.mean():.1f}%), n={novf.mean():.0f}, {ovf.mean()/max(novf.mean(),1):.0f} cyc/call')
+stamps = ws[need - nwg * 7 * 64:need] if wide else ws[:nwg * 7 * 64]
+d = stamps.view(torch.int64).cpu().numpy().reshape(nwg * 7, 8).astype(np.float64)
+d = d[d[:, 0] > 0]
+tot = d[:, 0].mean()
+if wide:
+    print(f'per wave (mean over {len(d)} waves): total {tot:.3g} cyc | tile wait {d[:,1].mean():.3g} ({100*d[:,1].mean()/tot:.1f}%) | '
+          f'candidate blocks {d[:,2].mean():.3g} ({100*d[:,2].mean()/tot:.1f}%), blocks={d[:,4].mean():.0f}, candidates={d[:,3].mean():.0f}, '
+          f'{d[:,2].mean()/max(d[:,4].mean(),1):.0f} cyc/block | compactions {d[:,6].mean():.3g} ({100*d[:,6].mean()/tot:.1f}%), n={d[:,5].mean():.0f}')
+else:
+    print(f'per wave (mean over {len(d)} waves): total {tot:.3g} cyc | tile wait {d[:,1].mean():.3g} ({100*d[:,1].mean()/tot:.1f}%) | '
+          f'event blocks {d[:,2].mean():.3g} ({100*d[:,2].mean()/tot:.1f}%), n={d[:,4].mean():.0f} | overflow {d[:,3].mean():.3g} '
+          f'({100*d[:,3].mean()/tot:.1f}%), n={d[:,5].mean():.0f}')
