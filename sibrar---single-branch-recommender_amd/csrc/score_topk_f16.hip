@@ -407,7 +407,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
 #define S3_ROWS (S3_WAVES * 64)
 #define S3_THREADS ((S3_WAVES + 1) * 64)
 #define S3_CAP 128                       // candidate buffer entries per user (global workspace)
-#define S3_LIMIT (S3_CAP - 64)           // fill above which a row is compacted before the next tile
 
 // All 64 lanes of the owning wave: keep the k best of the first n (<= 128, wave-uniform) entries of the global row buffer b
 // (lane l holds entries l and l + 64) at b[0..min(n, k)), UNSORTED, and return the new threshold (-inf while fewer than k
@@ -457,15 +456,15 @@ __device__ __forceinline__ float s3_select(unsigned long long* b, int n_any, int
   return st_key2f(T);
 }
 
-template <int KS, int NS, int DBG>   // KS = D / 16; NS = LDS ring slots; DBG: 1 = MFMA loop only, 2 = + threshold compares
+template <int KS, int NS, int NJ, int DBG>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations
 __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
     const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k,
     float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ gbuf,
     unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
-  constexpr int ST_TILE = 64;
-  constexpr int NJ = 2;
+  constexpr int ST_TILE = 32 * NJ;
+  constexpr int LIMIT = S3_CAP - ST_TILE;                  // fill above which a row is compacted before the next tile
   constexpr int ROWB = D * 2;
   constexpr int TILEB = ST_TILE * ROWB;
   constexpr int CPR = D / 8;
@@ -584,8 +583,8 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
   const unsigned long long t_begin = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int tl = 0; tl < n_tiles; ++tl) {
     const int slot = tl % NS;
-    if (__ballot(hw > S3_LIMIT)) {
-      // ---- maintenance (cold): compact the rows above S3_LIMIT so that this tile's appends cannot overflow
+    if (__ballot(hw > LIMIT)) {
+      // ---- maintenance (cold): compact the rows above LIMIT so that this tile's appends cannot overflow
       const unsigned long long tm0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
       }
       st_wave_fence();
       const int myfill = wfill[lane];
-      unsigned long long need = __ballot(myfill > S3_LIMIT);
+      unsigned long long need = __ballot(myfill > LIMIT);
       const unsigned long long done = need;
       while (need) {
         const int row = __ffsll((long long)need) - 1;
@@ -632,7 +631,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
     if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;
     const unsigned char* cur = smem + slot * TILEB;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];     // [2][NJ] used (a template-dependent array bound makes hipcc drop the host stub)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
         acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[1][s], b, acc[1][nj], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0][0]), "v"(acc[0][NJ - 1]), "v"(acc[1][0]), "v"(acc[1][NJ - 1]) : "memory");
     if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);
 
     // exclusions of this tile: one bit per excluded (row, column) for the lane that holds that accumulator — lane
@@ -685,7 +684,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
       e_pending = true;
     }
     if constexpr (DBG == 1) {
-      asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][NJ - 1]), "v"(acc[1][0]), "v"(acc[1][NJ - 1]));
       continue;
     }
     const bool have_ex = __ballot(wrote_ex) != 0ull;
@@ -782,7 +781,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
   }
 }
 
-template <int KS, int NS>
+template <int KS, int NS, int NJ>
 static int s3_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
   const long rows_padded = sbr_cdiv(Bu, S3_ROWS) * (long)S3_ROWS;
@@ -790,11 +789,11 @@ static int s3_launch(const void* U, const void* It, long Bu, int I, const long* 
   SBR_REQUIRE(workspace && workspace_bytes >= need + (getenv("SBR_ST_DEBUG") && atoi(getenv("SBR_ST_DEBUG")) == 4 ? sbr_cdiv(Bu, S3_ROWS) * S3_WAVES * 64L : 0L),
               "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", need, workspace_bytes);
   void* dbg_buf = (char*)workspace + need;
-  const size_t lds = (size_t)NS * 64 * KS * 32 + S3_WAVES * 64 * 20 + 2 * NS * 4 + 16;
+  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + S3_WAVES * 64 * 20 + 2 * NS * 4 + 16;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
   const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations (see above)
-  auto kern = dbg == 1 ? score_topk_f16_wide_kernel<KS, NS, 1> : (dbg == 2 ? score_topk_f16_wide_kernel<KS, NS, 2> :
-              (dbg == 4 ? score_topk_f16_wide_kernel<KS, NS, 4> : score_topk_f16_wide_kernel<KS, NS, 0>));
+  auto kern = dbg == 1 ? score_topk_f16_wide_kernel<KS, NS, NJ, 1> : (dbg == 2 ? score_topk_f16_wide_kernel<KS, NS, NJ, 2> :
+              (dbg == 4 ? score_topk_f16_wide_kernel<KS, NS, NJ, 4> : score_topk_f16_wide_kernel<KS, NS, NJ, 0>));
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
@@ -850,10 +849,11 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
   // D <= 128: the 64-users-per-wave kernel (SBR_SCORER_V1=1 keeps the first kernel for A/B timing). D = 256 stays on the first
-  // kernel: two A fragment sets would need 128 VGPRs.
+  // kernel: two A fragment sets need 128 VGPRs; the wide kernel with 32-item tiles (<16, 6, 1>) spills A fragments to scratch
+  // and reloads them inside the MFMA loop — measured 3.90 / 4.28 ms against 3.72 / 3.79 ms on 100k x 25k x 256.
   if (st_use_wide(D)) {
-    if (D == 128) return s3_launch<8, 6>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    return s3_launch<4, 8>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    if (D == 128) return s3_launch<8, 6, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    return s3_launch<4, 8, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
   }
   switch (D) {
     case 64: return st_launch<4, 6, 64>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, s);
