@@ -304,6 +304,37 @@ def test_fused_f16_scorer_ties_and_short_catalogues(D):
     assert np.isneginf(val.cpu().numpy()[:, 7:]).all()
 
 
+@pytest.mark.parametrize('bias', ['periodic_high', 'periodic_low', 'none'])
+def test_fused_f16_scorer_periodic_catalogues(bias):
+    """16k-item catalogue in which every 16th tile of 64 items holds ALL the highest (or all the lowest) scores: bursts of
+    candidates for every row at the same time, long stretches without any — the candidate buffers fill and compact in
+    lockstep. Exclusions on; compared with the fp64 reference."""
+    ops = S().ops
+    import scipy.sparse as sp
+    Bu, I, D, k = 600, 16384, 128, 20
+    g = torch.Generator().manual_seed(17)
+    u = (torch.randn(Bu, D, generator=g) / 4)
+    u[:, 0] = 1.0
+    it = (torch.randn(I, D, generator=g) / 8)
+    marked = ((torch.arange(I) // 64) % 16 == 0)
+    it[:, 0] = 0.0
+    if bias == 'periodic_high':
+        it[marked, 0] = 8.0
+    elif bias == 'periodic_low':
+        it[marked, 0] = -8.0
+    m = sp.random(Bu, I, density=0.004, format='csr', random_state=9)
+    m.sort_indices()
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(DEV)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(DEV)
+    uidx = torch.arange(Bu, device=DEV)
+    val, idx = ops.score_topk_f16(u.half().to(DEV), it.half().to(DEV), k, uidx, indptr, indices)
+    ref = (u.half().double() @ it.half().double().t())
+    ref[torch.from_numpy(m.toarray() != 0)] = -float('inf')
+    tv, ti = torch.topk(ref, k, sorted=True)
+    close(val.cpu(), tv, rtol=1e-5, atol=1e-5, what='values')
+    close(torch.gather(ref, 1, idx.cpu().long()), tv, rtol=1e-5, atol=1e-5, what='indices')
+
+
 def test_rank_metrics_vs_oracle():
     ops = S().ops
     from oracle import eval_ref
