@@ -122,3 +122,50 @@ def dataset_uniform(choices: np.ndarray, size: int, positive_indices: np.ndarray
     raw = np.random.choice(len(choices) - len(pos), size=size, replace=False)
     shifted = pos - np.arange(len(pos))
     return choices[raw + np.searchsorted(shifted, raw, side='right')]
+
+
+def dataset_uniform_recbole(choices: np.ndarray, size: int, positive_indices: np.ndarray) -> np.ndarray:
+    """data/sampling.py:35-66 (negative_sample_uniform_recbole): draw POSITIONS in ``choices`` with ``np.random.randint`` and
+    redraw the ones that are ``in positive_indices`` — the reference tests the position itself against the positive item ids
+    (identical to testing the item only when ``choices`` is ``arange``); restated literally."""
+    n_choices, n_positive = len(choices), len(positive_indices)
+    if n_choices - n_positive < size:
+        raise ValueError(f'Not enough values in the range to sample "{size}" unique values.')
+    if (n_choices - n_positive) * 0.5 < size:
+        raise ValueError('Sampling is really inefficient either because the number of choices are small'
+                         'or the number of items to sample is too high.')
+    neg = np.full(size, fill_value=-1)
+    todo = list(range(size))
+    while len(todo):
+        neg[todo] = np.random.randint(low=0, high=n_choices, size=len(todo))
+        todo = [i for i, v in zip(todo, neg[todo]) if v in positive_indices]
+    return choices[neg]
+
+
+def dataset_popular(choices: np.ndarray, size: int, popularity_distribution: np.ndarray, squashing_factor: float,
+                    positive_indices: np.ndarray = None) -> np.ndarray:
+    """data/sampling.py:69-80 (negative_sample_popular): ``np.random.choice`` over the non-positive items with probabilities
+    popularity ** alpha, renormalised (with replacement)."""
+    if positive_indices is not None:
+        choices = np.setdiff1d(choices, positive_indices, assume_unique=True)
+    p = np.power(popularity_distribution[choices], squashing_factor)
+    p = p / p.sum()
+    return np.random.choice(choices, size=size, p=p)
+
+
+def dataset_sampler_collate(user_idx, pos_item_idx, n_neg, strategy, choices, positives_of_user, pop=None, alpha=1.0):
+    """TrainRecDataset.__getitem__ with use_dataset_negative_sampler (data/dataset.py:360-394) over the rows of one batch, in batch
+    order, followed by the default collate: -> (u [B], items [B, 1 + n_neg], labels [B, 1 + n_neg] float64)."""
+    items, labels = [], []
+    for u, i in zip(user_idx, pos_item_idx):
+        if strategy == 'uniform':
+            neg = dataset_uniform(choices, n_neg, positives_of_user[u])
+        elif strategy == 'uniform_recbole':
+            neg = dataset_uniform_recbole(choices, n_neg, positives_of_user[u])
+        elif strategy == 'popular':
+            neg = dataset_popular(choices, n_neg, pop, alpha, positives_of_user[u])
+        else:
+            raise ValueError(f'Sampling strategy "{strategy}" not yet supported.')
+        items.append(np.concatenate([[i], neg]))
+        labels.append(np.concatenate([np.array([1.]), np.zeros_like(neg, dtype=float)]))
+    return np.asarray(user_idx, dtype=np.int64), np.stack(items).astype(np.int64), np.stack(labels)

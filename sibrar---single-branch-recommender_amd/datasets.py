@@ -20,8 +20,8 @@ import scipy.sparse as sp
 import torch
 
 from .features import HostFeature
-from .sampling import (DevicePositiveIndex, PositiveIndex, is_arange, loader_epoch_order, recbole_negative_collate,
-                       uniform_negative_collate)
+from .sampling import (DevicePositiveIndex, PositiveIndex, dataset_sampler_collate, is_arange, loader_epoch_order,
+                       recbole_negative_collate, uniform_negative_collate)
 
 
 def synthetic_interactions(n_users: int, n_items: int, nnz: int, seed: int = 0) -> sp.csr_matrix:
@@ -113,7 +113,7 @@ class NegativeSamplingDataLoader:
 
     def __init__(self, dataset, batch_size: int = 256, shuffle: bool = True, strategy: Optional[str] = None,
                  rank: int = 0, world: int = 1, max_batches: Optional[int] = None, device=None, prefetch: int = 0,
-                 draw_fn=None, prepare_fn=None, dp_sampling: str = 'global'):
+                 draw_fn=None, prepare_fn=None, dp_sampling: str = 'global', use_dataset_negative_sampler: bool = False):
         """``device``: run the collision test of the collate on that GPU (DevicePositiveIndex) instead of numpy.
         ``prefetch`` > 0: a producer thread prepares up to that many batches ahead (single producer, so the RNG streams are
         consumed in the same order as without it).
@@ -128,7 +128,11 @@ class NegativeSamplingDataLoader:
         uploads on a side stream) — the 4th element is then a ready ``PreparedBatch``."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.strategy = strategy or dataset.negative_sampling_strategy
-        if self.strategy not in ('uniform_recbole', 'uniform'):
+        # ``use_dataset_negative_sampler``: the negatives come from the dataset-level samplers, one call per interaction in
+        # batch order (TrainRecDataset.__getitem__, data/dataset.py:379-394; strategies uniform / uniform_recbole / popular)
+        self.dataset_sampler = bool(use_dataset_negative_sampler)
+        allowed = ('uniform', 'uniform_recbole', 'popular') if self.dataset_sampler else ('uniform_recbole', 'uniform')
+        if self.strategy not in allowed:
             raise ValueError(f'sampling strategy {self.strategy} not supported for dataloader sampling!')
         self.n_neg = dataset.n_negative_samples
         coo = dataset.interaction_matrix
@@ -148,6 +152,7 @@ class NegativeSamplingDataLoader:
         self.prepare_fn = prepare_fn
         self._prepare_takes_key = None
         self._identity_items = is_arange(np.asarray(dataset.items_in_split))
+        self._pos_rows, self._pop = None, None
 
     def __len__(self):
         if self.dp_sampling == 'local' and self.world > 1:
@@ -257,7 +262,17 @@ class NegativeSamplingDataLoader:
             else:
                 lo = b * self.batch_size
             bu, bi = rows_e[lo:lo + self.batch_size], cols_e[lo:lo + self.batch_size]
-            if self.strategy == 'uniform_recbole':
+            if self.dataset_sampler:
+                if self._pos_rows is None:
+                    m = self.dataset.user_sampling_matrix
+                    self._pos_rows = [m.indices[m.indptr[r]:m.indptr[r + 1]] for r in range(m.shape[0])]
+                    if self.strategy == 'popular':
+                        pop = np.asarray(m.sum(axis=0)).flatten()
+                        self._pop = getattr(self.dataset, 'pop_distribution', pop / pop.sum())
+                u, i, l = dataset_sampler_collate(bu, bi, self.n_neg, self.strategy, np.asarray(self.dataset.items_in_split),
+                                                  self._pos_rows, self._pop,
+                                                  float(getattr(self.dataset, 'sampling_popularity_squashing_factor', 1.0)))
+            elif self.strategy == 'uniform_recbole':
                 u, i, l = recbole_negative_collate(bu, bi, self.n_neg, self.dataset.items_in_split, self.positives,
                                                    self._identity_items)
             else:

@@ -214,3 +214,80 @@ def uniform_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     n_pos = pos_item_idx.shape[-1] if np.ndim(pos_item_idx) > 1 else 1
     labels[:, :n_pos] = 1.
     return user_idx, items, labels
+
+
+# ---- dataset-level negative samplers (TrainRecDataset._get_negative_samples, data/dataset.py:360-374; data/sampling.py) ---------
+# Called per interaction when ``use_dataset_negative_sampler`` is set. Host-side index work on the global legacy numpy stream:
+# the results and the stream position afterwards are bit-identical to the reference's functions (tests/golden g13).
+def dataset_negative_uniform(choices: np.ndarray, size: int, positives: np.ndarray) -> np.ndarray:
+    """``negative_sample_uniform`` (data/sampling.py:7-32): ``size`` distinct non-positive items. The reference draws ranks
+    among the non-positive slots with ``np.random.choice(m, size, replace=False)`` (a permutation of all m slots on the legacy
+    stream — that call defines the stream and is kept) and shifts each rank past the positives below it."""
+    n_free = len(choices) - len(positives)
+    if n_free < size:
+        raise ValueError(f'Not enough values in the range to sample "{size}" unique values.')
+    slots = np.searchsorted(choices, positives)                  # positions of the positives inside `choices` (both sorted)
+    ranks = np.random.choice(n_free, size=size, replace=False)
+    return choices[ranks + np.searchsorted(slots - np.arange(len(slots)), ranks, side='right')]
+
+
+def dataset_negative_uniform_recbole(choices: np.ndarray, size: int, positives: np.ndarray) -> np.ndarray:
+    """``negative_sample_uniform_recbole`` (data/sampling.py:35-66): rejection sampling of positions in ``choices``; every round
+    redraws the colliding slots with one ``np.random.randint`` call (the stream), the Python ``v in positives`` loop is a
+    sorted-array membership test. As in the reference, the drawn POSITION is tested against the positive item ids."""
+    n, n_pos = len(choices), len(positives)
+    if n - n_pos < size:
+        raise ValueError(f'Not enough values in the range to sample "{size}" unique values.')
+    if (n - n_pos) * 0.5 < size:
+        raise ValueError('Sampling is really inefficient either because the number of choices are small'
+                         'or the number of items to sample is too high.')
+    pos_sorted = np.sort(np.asarray(positives))
+    neg = np.full(size, -1, dtype=np.int64)
+    todo = np.arange(size)
+    while todo.size:
+        neg[todo] = np.random.randint(low=0, high=n, size=todo.size)
+        at = np.searchsorted(pos_sorted, neg[todo])
+        hit = (at < n_pos) & (pos_sorted[np.minimum(at, max(n_pos - 1, 0))] == neg[todo]) if n_pos else np.zeros(todo.size, bool)
+        todo = todo[hit]
+    return choices[neg]
+
+
+def dataset_negative_popular(choices: np.ndarray, size: int, popularity: np.ndarray, alpha: float,
+                             positives: Optional[np.ndarray] = None) -> np.ndarray:
+    """``negative_sample_popular`` (data/sampling.py:69-80): with replacement, probability ~ popularity ** alpha over the
+    non-positive items. ``np.random.choice(a, size, p=p)`` on the legacy stream is ``a[searchsorted(cumsum(p) / cumsum(p)[-1],
+    random_sample(size), 'right')]``; written out so that the per-user work is one mask, one power and one cumsum."""
+    if positives is not None:
+        keep = np.ones(len(choices), dtype=bool)
+        at = np.searchsorted(choices, positives)
+        ok = at < len(choices)
+        ok[ok] &= choices[at[ok]] == np.asarray(positives)[ok]
+        keep[at[ok]] = False
+        choices = choices[keep]
+    p = np.power(popularity[choices], alpha)
+    p = p / p.sum()
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    return choices[np.searchsorted(cdf, np.random.random_sample(size), side='right')]
+
+
+def dataset_sampler_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_neg: int, strategy: str, choices: np.ndarray,
+                            positives_of_user, popularity: Optional[np.ndarray] = None, alpha: float = 1.0):
+    """One batch of ``TrainRecDataset.__getitem__`` with ``use_dataset_negative_sampler`` (data/dataset.py:379-394) + the default
+    collate: rows are sampled in batch order. -> (u [B] int64, items [B, 1 + n_neg] int64, labels [B, 1 + n_neg] float64)."""
+    B = len(user_idx)
+    items = np.empty((B, 1 + n_neg), dtype=np.int64)
+    items[:, 0] = pos_item_idx
+    for r in range(B):
+        pos = positives_of_user[int(user_idx[r])]
+        if strategy == 'uniform':
+            items[r, 1:] = dataset_negative_uniform(choices, n_neg, pos)
+        elif strategy == 'uniform_recbole':
+            items[r, 1:] = dataset_negative_uniform_recbole(choices, n_neg, pos)
+        elif strategy == 'popular':
+            items[r, 1:] = dataset_negative_popular(choices, n_neg, popularity, alpha, pos)
+        else:
+            raise ValueError(f'Sampling strategy "{strategy}" not yet supported.')
+    labels = np.zeros((B, 1 + n_neg), dtype=np.float64)
+    labels[:, 0] = 1.
+    return np.asarray(user_idx, dtype=np.int64), items, labels

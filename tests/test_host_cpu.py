@@ -292,3 +292,49 @@ def test_split_loader_matches_reference_datasets(name, split):
             else:
                 got = np.asarray(f.values, dtype=np.float64).reshape(len(want), -1)
                 assert np.allclose(got, np.asarray(want, dtype=np.float64).reshape(len(want), -1))
+
+
+@pytest.mark.parametrize('choice_set', ['all', 'subset'])
+def test_dataset_level_samplers_match_reference_streams(choice_set):
+    """Product-side dataset-level samplers (sampling.dataset_negative_*; a20 (ii) + (iv)) == the reference's streams (g13:
+    values and generator position), and the loader's per-interaction mode == the oracle's literal collate."""
+    from importlib import import_module
+    import sibrar_amd as S
+    from oracle import sampling_ref
+    sampling = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.sampling')
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g13_dataset_samplers.npz'))
+    w = world(load('g6_neg_sampling'))
+    inter = w['inter']
+    choices = z[f'{choice_set}/choices']
+    pos = [np.intersect1d(inter[u].indices, choices) for u in range(10)]
+    pop = z['pop_distribution']
+    for name, fn in (('uniform', lambda u: sampling.dataset_negative_uniform(choices, 3, pos[u])),
+                     ('uniform_recbole', lambda u: sampling.dataset_negative_uniform_recbole(choices, 3, pos[u])),
+                     ('popular_1.0', lambda u: sampling.dataset_negative_popular(choices, 3, pop, 1.0, pos[u])),
+                     ('popular_0.75', lambda u: sampling.dataset_negative_popular(choices, 3, pop, 0.75, pos[u]))):
+        np.random.seed(42)
+        got = np.stack([fn(u) for u in range(10)])
+        assert np.array_equal(got, z[f'{choice_set}/{name}']), name
+        assert np.array_equal(np.random.randint(0, 1000, size=4), z[f'{choice_set}/after_{name}']), name
+    if choice_set == 'subset':
+        return
+    ds = S.SyntheticDataset.__new__(S.SyntheticDataset)
+    ds.interaction_matrix = inter.tocoo()
+    ds.user_sampling_matrix = inter
+    ds.items_in_split = np.arange(I)
+    ds.n_items = I
+    ds.n_negative_samples = 3
+    ds.sampling_popularity_squashing_factor = 0.75
+    positives = [inter[u].indices for u in range(U)]
+    for strategy in ('uniform', 'uniform_recbole', 'popular'):
+        ds.negative_sampling_strategy = strategy
+        sampling_ref.reproducible(42)
+        loader = S.NegativeSamplingDataLoader(ds, batch_size=16, shuffle=True, use_dataset_negative_sampler=True)
+        batches = [b for _, b in zip(range(3), loader)]
+        sampling_ref.reproducible(42)
+        perm = sampling_ref.loader_epoch_order(ds.interaction_matrix.nnz)
+        for b, (u, i, l) in enumerate(batches):
+            sel = perm[b * 16:(b + 1) * 16]
+            ru, ri, rl = sampling_ref.dataset_sampler_collate(ds.interaction_matrix.row[sel], ds.interaction_matrix.col[sel], 3, strategy,
+                                                              np.arange(I), positives, pop, 0.75)
+            assert np.array_equal(u.numpy(), ru) and np.array_equal(i.numpy(), ri) and np.array_equal(l.numpy(), rl), strategy
