@@ -147,6 +147,14 @@ int sbr_score_dot_bwd(const float* G, const float* U, const float* I, float* dU,
 /* SGDBaseline — algorithms/sgd_alg.py:110-119 */
 int sbr_bias_score_fwd(const float* user_bias, const float* item_bias, const float* global_bias, const long* u, const long* i,
                        float* out, long B, int N, void* stream);
+/* bias terms of SGDMatrixFactorization.combine_user_item_representations — algorithms/sgd_alg.py:186-194 (and SGDBaseline in
+ * training): out[b, n] = base[b, n] + user_bias[u[b]] + item_bias[i[b, n]] + global_bias[0]; every term may be NULL; u NULL: row b,
+ * i NULL: column n (all-pairs scoring against a gathered bias vector). Backward: the bias-table gradients are accumulated
+ * (zero-initialise them), NULL ones skipped; d base = g. */
+int sbr_bias_score_add_fwd(const float* user_bias, const float* item_bias, const float* global_bias, const long* u, const long* i,
+                           const float* base, float* out, long B, int N, void* stream);
+int sbr_bias_score_bwd(const float* g, const long* u, const long* i, float* d_user_bias, float* d_item_bias, float* d_global_bias,
+                       long B, int N, void* stream);
 
 /* ---- BatchNorm1d (+ fused activation) — modules/polylinear.py:61,68; algorithms/sgd_alg.py:1837 ---------------------------
  * ws: 34*D doubles of workspace (2*D totals + 16 replicas that spread the per-block atomics); ZERO on first use, every call

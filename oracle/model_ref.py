@@ -11,6 +11,7 @@ Reference files followed (relative to /root/reference):
   algorithms/sgd_alg.py:1764-2006        -> ``RefEntity``
   algorithms/sgd_alg.py:2009-2144        -> ``RefSingleBranchNet``
   algorithms/sgd_alg.py:88-123           -> ``sgd_baseline_logits``
+  algorithms/sgd_alg.py:126-200          -> ``mf_logits``
   data/Feature.py:140-162                -> ``RefTable.rows``
 """
 from __future__ import annotations
@@ -372,6 +373,22 @@ class RefSingleBranchNet:
 def sgd_baseline_logits(sd, u_idx: torch.Tensor, i_idx: torch.Tensor) -> torch.Tensor:
     """SGDBaseline (sgd_alg.py:110-119): user_bias[u] + item_bias[i].squeeze() + global_bias."""
     return sd['user_bias.weight'][u_idx] + sd['item_bias.weight'][i_idx].squeeze() + sd['global_bias']
+
+
+def mf_logits(sd, u_idx: torch.Tensor, i_idx: torch.Tensor) -> torch.Tensor:
+    """SGDMatrixFactorization (sgd_alg.py:159-194): (u_embed[:, None, :] * i_embed).sum(-1) [+ item_bias[i].squeeze()]
+    [+ global_bias]; ``i_idx`` [B, N] (training) or [I] (all-pairs, the evaluation path eval/eval.py:209-217). A ``user_bias``
+    in the state dict raises like the reference's in-place add of a [B, 1, 1] tensor to [B, N] (:190)."""
+    u_embed = sd['user_embeddings.weight'][u_idx]
+    i_embed = sd['item_embeddings.weight'][i_idx]
+    out = (u_embed[:, None, :] * i_embed).sum(dim=-1)
+    if 'user_bias.weight' in sd:
+        out += sd['user_bias.weight'][u_idx][:, None]
+    if 'item_bias.weight' in sd:
+        out = out + sd['item_bias.weight'][i_idx].squeeze()
+    if 'global_bias' in sd:
+        out = out + sd['global_bias']
+    return out
 
 
 def init_state_dict(shapes: Dict[str, tuple], seed: int = 42) -> Dict[str, torch.Tensor]:

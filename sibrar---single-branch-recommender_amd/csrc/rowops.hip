@@ -833,6 +833,60 @@ extern "C" int sbr_bias_score_fwd(const float* user_bias, const float* item_bias
   return SBR_OK;
 }
 
+// Bias terms of the factorisation models (SGDMatrixFactorization.combine, sgd_alg.py:186-194; SGDBaseline, :110-119), forward
+// and backward: out[b, n] = base[b, n] + user_bias[u[b]] + item_bias[i[b, n]] + global_bias, every term optional. u == null:
+// row b itself; i == null: column n itself (all-pairs scoring against an already gathered bias vector).
+__global__ void bias_score_add_kernel(const float* __restrict__ ub, const float* __restrict__ ib, const float* __restrict__ gb,
+                                      const long* __restrict__ u, const long* __restrict__ i, const float* __restrict__ base,
+                                      float* __restrict__ out, long B, int N) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= B * N) return;
+  const long b = e / N;
+  float v = base ? base[e] : 0.f;
+  if (ub) v += ub[u ? u[b] : b];
+  if (ib) v += ib[i ? i[e] : e - b * N];
+  if (gb) v += gb[0];
+  out[e] = v;
+}
+
+extern "C" int sbr_bias_score_add_fwd(const float* user_bias, const float* item_bias, const float* global_bias, const long* u,
+                                      const long* i, const float* base, float* out, long B, int N, void* stream) {
+  if (B * N == 0) return SBR_OK;
+  SBR_REQUIRE(out, "sbr_bias_score_add_fwd: null output");
+  bias_score_add_kernel<<<sbr_cdiv(B * N, 256), 256, 0, (hipStream_t)stream>>>(user_bias, item_bias, global_bias, u, i, base, out, B, N);
+  SBR_CHECK_LAUNCH("sbr_bias_score_add_fwd");
+  return SBR_OK;
+}
+
+// gradients of the bias tables (ACCUMULATED: zero-initialised by the caller); the gradient of `base` is g itself
+__global__ void bias_score_bwd_kernel(const float* __restrict__ g, const long* __restrict__ u, const long* __restrict__ i,
+                                      float* __restrict__ d_ub, float* __restrict__ d_ib, float* __restrict__ d_gb, long B, int N) {
+  __shared__ float part[4];
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  float v = 0.f;
+  if (e < B * N) {
+    v = g[e];
+    const long b = e / N;
+    if (d_ub) atomicAdd(&d_ub[u ? u[b] : b], v);
+    if (d_ib) atomicAdd(&d_ib[i ? i[e] : e - b * N], v);
+  }
+  if (d_gb) {                                                 // block sum -> one atomic per block
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(d_gb, part[0] + part[1] + part[2] + part[3]);
+  }
+}
+
+extern "C" int sbr_bias_score_bwd(const float* g, const long* u, const long* i, float* d_user_bias, float* d_item_bias,
+                                  float* d_global_bias, long B, int N, void* stream) {
+  if (B * N == 0) return SBR_OK;
+  SBR_REQUIRE(g, "sbr_bias_score_bwd: null operand");
+  bias_score_bwd_kernel<<<sbr_cdiv(B * N, 256), 256, 0, (hipStream_t)stream>>>(g, u, i, d_user_bias, d_item_bias, d_global_bias, B, N);
+  SBR_CHECK_LAUNCH("sbr_bias_score_bwd");
+  return SBR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // membership test of (row, col) pairs in a CSR matrix with sorted column indices — the `v in positives` test of the
 // negative-sampling collate (data/dataloader.py:184-191), evaluated for all still-colliding slots of a batch at once.

@@ -310,6 +310,62 @@ class ScoreDotFn(Function):
         return du, di
 
 
+class LookupFn(Function):
+    """nn.Embedding (dense gradient) — sgd_alg.py:144-145, 159-167: out[..., :] = W[idx[...], :]; dW is the dense scatter-add."""
+
+    @staticmethod
+    def forward(ctx, W, idx):
+        _need_cuda(W, idx)
+        if W.stride(-1) != 1:
+            W = W.contiguous()
+        rows = idx.reshape(-1).to(torch.int32).contiguous()
+        n, D = rows.numel(), W.shape[1]
+        out = torch.empty(n, D, device=W.device, dtype=torch.float32)
+        call('sbr_gather_rows', ptr(W), W.stride(0), ptr(rows), ptr(out), D, None, n, D, stream())
+        ctx.save_for_backward(rows)
+        ctx.w_shape = W.shape
+        return out.view(*idx.shape, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        D = ctx.w_shape[1]
+        g = _f32c(g).reshape(-1, D)
+        dW = torch.zeros(ctx.w_shape, device=g.device, dtype=torch.float32)
+        call('sbr_scatter_add_rows', ptr(g), D, None, ptr(rows), ptr(dW), D, rows.numel(), D, stream())
+        return dW, None
+
+
+class BiasScoreFn(Function):
+    """out[b, n] = base[b, n] + user_bias[u[b]] + item_bias[i[b, n]] + global_bias (sgd_alg.py:186-194, 110-119); every term
+    optional (None). Bias tables are 1-D float views of the [n, 1] embedding weights. u None: row b; i None: column n."""
+
+    @staticmethod
+    def forward(ctx, base, ub, ib, gb, u, i, B, N):
+        dev = next(t for t in (base, ub, ib, gb) if t is not None).device
+        base_c = _f32c(base) if base is not None else None
+        u_c = u.long().contiguous() if u is not None else None
+        i_c = i.long().contiguous() if i is not None else None
+        out = torch.empty(B, N, device=dev, dtype=torch.float32)
+        call('sbr_bias_score_add_fwd', ptr(ub), ptr(ib), ptr(gb), ptr(u_c), ptr(i_c), ptr(base_c), ptr(out), B, N, stream())
+        ctx.save_for_backward(u_c, i_c)
+        ctx.shapes = (None if ub is None else ub.shape, None if ib is None else ib.shape, gb is not None, base is not None, B, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u_c, i_c = ctx.saved_tensors
+        ub_s, ib_s, has_gb, has_base, B, N = ctx.shapes
+        g = _f32c(g)
+        need = ctx.needs_input_grad
+        d_ub = torch.zeros(ub_s, device=g.device, dtype=torch.float32) if ub_s is not None and need[1] else None
+        d_ib = torch.zeros(ib_s, device=g.device, dtype=torch.float32) if ib_s is not None and need[2] else None
+        d_gb = torch.zeros(1, device=g.device, dtype=torch.float32) if has_gb and need[3] else None
+        if d_ub is not None or d_ib is not None or d_gb is not None:
+            call('sbr_bias_score_bwd', ptr(g), ptr(u_c), ptr(i_c), ptr(d_ub), ptr(d_ib), ptr(d_gb), B, N, stream())
+        return (g if has_base and need[0] else None), d_ub, d_ib, d_gb, None, None, None, None
+
+
 class ScoreAllFn(Function):
     """einsum('be,ce->bc') — sgd_alg.py:2109: all users of the batch against all item representations."""
 

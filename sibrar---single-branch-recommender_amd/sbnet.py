@@ -639,22 +639,108 @@ class SGDBaseline(SGDBasedRecommenderAlgorithm):
         self.name = 'SGDBaseline'
 
     def get_user_representations(self, u_idxs):
-        return self.user_bias(u_idxs)
+        return ops.LookupFn.apply(self.user_bias.weight, u_idxs)
 
     def get_item_representations(self, i_idxs):
-        return self.item_bias(i_idxs).squeeze()
+        return ops.LookupFn.apply(self.item_bias.weight, i_idxs).squeeze()
 
     def combine_user_item_representations(self, u_repr, i_repr):
-        return u_repr + i_repr + self.global_bias
+        # u_repr [B, 1], i_repr [B, N] (training) or [I] (evaluation, eval/eval.py:209-217): gathered values, no further lookup
+        N = i_repr.shape[-1]
+        B = u_repr.shape[0]
+        base = i_repr.contiguous() if i_repr.ndim == 2 else None
+        return ops.BiasScoreFn.apply(base, u_repr.reshape(-1), None if i_repr.ndim == 2 else i_repr.contiguous(),
+                                     self.global_bias, None, None, B, N)
 
     def forward(self, u_idxs, i_idxs):
-        if i_idxs.is_cuda and i_idxs.ndim == 2 and not torch.is_grad_enabled():
-            out = torch.empty(i_idxs.shape, device=i_idxs.device, dtype=torch.float32)
-            call('sbr_bias_score_fwd', ptr(self.user_bias.weight), ptr(self.item_bias.weight), ptr(self.global_bias),
-                 ptr(u_idxs.long().contiguous()), ptr(i_idxs.long().contiguous()), ptr(out), i_idxs.shape[0], i_idxs.shape[1], stream())
-            return out
+        if not i_idxs.is_cuda:
+            raise RuntimeError('SGDBaseline (HIP engine) needs CUDA(HIP) index tensors')
+        if i_idxs.ndim == 2:                               # one fused kernel forward, one backward
+            B, N = i_idxs.shape
+            return ops.BiasScoreFn.apply(None, self.user_bias.weight.view(-1), self.item_bias.weight.view(-1), self.global_bias,
+                                         u_idxs, i_idxs, B, N)
         return super().forward(u_idxs, i_idxs)
 
     @staticmethod
     def build_from_conf(conf: dict, dataset):
         return SGDBaseline(dataset.n_users, dataset.n_items)
+
+
+class SGDMatrixFactorization(SGDBasedRecommenderAlgorithm):
+    """algorithms/sgd_alg.py:126-200 — matrix factorisation trained by gradient descent (a sibling model that
+    runs on the hot path's kernels): embedding lookups (``sbr_gather_rows`` / dense ``sbr_scatter_add_rows``), the per-slot dot
+    product of the SingleBranchNet scorer (``sbr_score_dot_*``) or the all-pairs MFMA GEMM in evaluation, bias terms
+    (``sbr_bias_score_*``). state_dict keys as in the reference: user_embeddings.weight, item_embeddings.weight,
+    [user_bias.weight], [item_bias.weight], [global_bias]."""
+
+    def __init__(self, n_users: int, n_items: int, embedding_dim: int = 100, use_user_bias: bool = False,
+                 use_item_bias: bool = False, use_global_bias: bool = False):
+        super().__init__()
+        self.n_users, self.n_items, self.embedding_dim = n_users, n_items, embedding_dim
+        self.use_user_bias, self.use_item_bias, self.use_global_bias = use_user_bias, use_item_bias, use_global_bias
+        self.user_embeddings = nn.Embedding(n_users, embedding_dim)
+        self.item_embeddings = nn.Embedding(n_items, embedding_dim)
+        if use_user_bias:
+            self.user_bias = nn.Embedding(n_users, 1)
+        if use_item_bias:
+            self.item_bias = nn.Embedding(n_items, 1)
+        self.apply(general_weight_init)
+        if use_global_bias:
+            self.global_bias = nn.Parameter(torch.zeros(1), requires_grad=True)
+        self.name = 'SGDMatrixFactorization'
+
+    def get_user_representations(self, u_idxs):
+        emb = ops.LookupFn.apply(self.user_embeddings.weight, u_idxs)
+        if self.use_user_bias:
+            return emb, ops.LookupFn.apply(self.user_bias.weight, u_idxs)
+        return emb
+
+    def get_item_representations(self, i_idxs):
+        emb = ops.LookupFn.apply(self.item_embeddings.weight, i_idxs)
+        if self.use_item_bias:
+            return emb, ops.LookupFn.apply(self.item_bias.weight, i_idxs).squeeze()
+        return emb
+
+    def _check_user_bias(self):
+        if self.use_user_bias:
+            # the reference adds u_bias[:, None] ([B, 1, 1]) in place to the [B, N] scores (sgd_alg.py:190): a RuntimeError
+            raise RuntimeError("output with shape [B, N] doesn't match the broadcast shape [B, B, N] "
+                               '(use_user_bias: the reference raises here, algorithms/sgd_alg.py:190)')
+
+    def combine_user_item_representations(self, u_repr, i_repr):
+        u_embed = u_repr[0] if isinstance(u_repr, tuple) else u_repr
+        i_embed, i_bias = i_repr if isinstance(i_repr, tuple) else (i_repr, None)
+        if i_embed.ndim == 3 and i_embed.shape[0] == 1:    # [1, I, D]: broadcast over users like the reference's product
+            i_embed = i_embed[0]
+            i_bias = i_bias.reshape(-1) if i_bias is not None else None
+        out = (ops.ScoreDotFn if i_embed.ndim == 3 else ops.ScoreAllFn).apply(u_embed, i_embed)
+        self._check_user_bias()
+        if i_bias is None and not self.use_global_bias:
+            return out
+        B, N = out.shape
+        gb = self.global_bias if self.use_global_bias else None
+        if i_bias is None or i_bias.ndim == 2:             # per-slot biases are already [B, N]: part of the base
+            base = out if i_bias is None else out + i_bias
+            return ops.BiasScoreFn.apply(base, None, None, gb, None, None, B, N)
+        return ops.BiasScoreFn.apply(out, None, i_bias.contiguous(), gb, None, None, B, N)
+
+    def forward(self, u_idxs, i_idxs):
+        if not i_idxs.is_cuda:
+            raise RuntimeError('SGDMatrixFactorization (HIP engine) needs CUDA(HIP) index tensors')
+        if i_idxs.ndim != 2:
+            return super().forward(u_idxs, i_idxs)
+        # training path: lookups, per-slot dot, bias terms — every step a HIP kernel with its hand-written backward
+        u_embed = ops.LookupFn.apply(self.user_embeddings.weight, u_idxs)
+        i_embed = ops.LookupFn.apply(self.item_embeddings.weight, i_idxs)
+        out = ops.ScoreDotFn.apply(u_embed, i_embed)
+        self._check_user_bias()
+        if not (self.use_item_bias or self.use_global_bias):
+            return out
+        B, N = i_idxs.shape
+        return ops.BiasScoreFn.apply(out, None, self.item_bias.weight.view(-1) if self.use_item_bias else None,
+                                     self.global_bias if self.use_global_bias else None, None, i_idxs, B, N)
+
+    @staticmethod
+    def build_from_conf(conf: dict, dataset):
+        return SGDMatrixFactorization(dataset.n_users, dataset.n_items, conf['embedding_dim'], conf['use_user_bias'],
+                                      conf['use_item_bias'], conf['use_global_bias'])

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""G14: sibling models that reuse the hot path's kernels, generated with the REAL reference.
+
+    PYTHONHASHSEED=0 python tests/golden/make_golden_siblings.py      (build container only)
+
+SGDMatrixFactorization (algorithms/sgd_alg.py:126-200) with every bias combination used by the reference's configs, and
+SGDBaseline (:88-123): parameters, one batch, train-mode logits, BPR loss (train/rec_losses.py:63-83), the gradient of every
+parameter, and eval-mode all-pairs scores through get_*_representations + combine (the evaluation path, eval/eval.py:205-217).
+Only data is written.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G  # noqa: E402  (installs the import placeholders, asserts PYTHONHASHSEED=0)
+
+import torch  # noqa: E402
+from algorithms.sgd_alg import SGDMatrixFactorization, SGDBaseline  # noqa: E402
+from train.rec_losses import RecBayesianPersonalizedRankingLoss  # noqa: E402
+
+U, I = G.U, G.I
+arrays, meta = {}, {'cases': []}
+u, i, labels = G.batch(14)
+arrays['u'], arrays['i'], arrays['labels'] = G.t2n(u), G.t2n(i), G.t2n(labels)
+loss_fn = RecBayesianPersonalizedRankingLoss(n_items=I, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+
+
+def record(name, m):
+    with torch.no_grad():
+        for p_name, p in m.named_parameters():
+            if 'bias' in p_name:                      # biases initialise to ~0: give them signal
+                p.copy_(torch.randn_like(p) * 0.3)
+    arrays.update(G.sd2n(m.state_dict(), f'{name}/sd/'))
+    m.train()
+    logits = m(u, i)
+    loss = loss_fn.compute_loss(logits, labels)
+    loss.backward()
+    arrays[f'{name}/logits'] = G.t2n(logits)
+    arrays[f'{name}/loss'] = G.t2n(loss)
+    for p_name, p in m.named_parameters():
+        arrays[f'{name}/grad/{p_name}'] = G.t2n(p.grad)
+    m.eval()
+    with torch.no_grad():
+        all_items = torch.arange(I)
+        ir = m.get_item_representations(all_items)
+        ur = m.get_user_representations(u)
+        if name.startswith('mf'):
+            # eval/eval.py:205-217 path: item representations once, combine per user batch
+            i_arg = tuple(r[None] if r.ndim < 2 else r[None] for r in ir) if isinstance(ir, tuple) else ir[None]
+            arrays[f'{name}/scores_all'] = G.t2n(m.combine_user_item_representations(ur, i_arg))
+        else:
+            arrays[f'{name}/scores_all'] = G.t2n(m(u, all_items[None].expand(len(u), -1)))
+
+
+# use_user_bias=True raises in the reference's combine (sgd_alg.py:190: a [B, 1] bias indexed [:, None] is added in place to [B, N])
+for ub, ib, gb in ((False, False, False), (False, True, True), (False, True, False), (False, False, True)):
+    torch.manual_seed(14)
+    name = f'mf_u{int(ub)}i{int(ib)}g{int(gb)}'
+    record(name, SGDMatrixFactorization(U, I, embedding_dim=8, use_user_bias=ub, use_item_bias=ib, use_global_bias=gb))
+    meta['cases'].append({'name': name, 'use_user_bias': ub, 'use_item_bias': ib, 'use_global_bias': gb, 'embedding_dim': 8})
+torch.manual_seed(15)
+record('baseline', SGDBaseline(U, I))
+np.savez_compressed(os.path.join(HERE, 'g14_sibling_models.npz'), **arrays)
+json.dump(meta, open(os.path.join(HERE, 'g14_sibling_models.json'), 'w'), indent=1)
+print(sorted(arrays)[:12], len(arrays))

@@ -241,6 +241,76 @@ def test_g11_sgd_baseline():
     close(m(u, i).detach().cpu(), z['logits'], what='logits(train)', **TOL)
 
 
+def _g14_cases():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g14_sibling_models.json')
+    return json.load(open(here))['cases']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', _g14_cases() + [{'name': 'baseline'}], ids=lambda c: c['name'])
+def test_g14_sibling_models_on_hip_kernels(case):
+    """SGDMatrixFactorization / SGDBaseline of the product (lookups, per-slot dot / all-pairs MFMA GEMM, bias kernels and their
+    hand-written backward) == the real reference: train-mode logits, BPR loss, every gradient, evaluation scores through
+    get_*_representations + combine (eval/eval.py:209-217); 3 AdamW steps == the oracle with torch.optim on the CPU."""
+    import sibrar_amd as S
+    from oracle import model_ref, losses_ref, train_ref
+    z = load('g14_sibling_models')
+    name = case['name']
+    if name == 'baseline':
+        m, fn = S.SGDBaseline(U, I), model_ref.sgd_baseline_logits
+    else:
+        m = S.SGDMatrixFactorization(U, I, case['embedding_dim'], case['use_user_bias'], case['use_item_bias'], case['use_global_bias'])
+        fn = model_ref.mf_logits
+    sd = state_dict(z, f'{name}/sd/')
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    u, i, labels = (torch.from_numpy(z[k]).to(DEV) for k in ('u', 'i', 'labels'))
+    logits = m(u, i)
+    close(logits.detach().cpu(), z[f'{name}/logits'], what='logits', **TOL)
+    loss = _loss('bpr').compute_loss(logits, labels)
+    close(loss.detach().cpu(), z[f'{name}/loss'], what='loss', **TOL)
+    loss.backward()
+    for k, p in m.named_parameters():
+        close(p.grad.cpu(), z[f'{name}/grad/{k}'], what=f'grad {k}', **TOL)
+    m.eval()
+    with torch.no_grad():
+        ir = m.get_item_representations(torch.arange(I, device=DEV))
+        scores = m.combine_user_item_representations(m.get_user_representations(u), ir)
+    close(scores.cpu(), z[f'{name}/scores_all'], what='all-pairs scores', **TOL)
+    # three optimizer steps against the oracle — with BCE: under BPR a global or user bias cancels in pos - neg, its gradient is
+    # rounding noise and Adam turns that noise into +-lr steps (see golden_util.bn_shadowed_biases for the same effect)
+    m.train()
+    m.zero_grad()
+    opt = S.FusedOptimizer(m, 'adamw', lr=1e-2, weight_decay=1e-2)
+    ref_sd = state_dict(z, f'{name}/sd/', requires_grad=True)
+    ref_opt = train_ref.make_optimizer('adamw', list(ref_sd.values()), 1e-2, 1e-2)
+    ref_loss = losses_ref.RefRecLoss('bce', n_items=I, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        bu = torch.from_numpy(rng.integers(0, U, size=16))
+        bi = torch.from_numpy(rng.integers(0, I, size=(16, 4)))
+        lab = torch.zeros(16, 4, dtype=torch.float64)
+        lab[:, 0] = 1
+        _loss('bce').compute_loss(m(bu.to(DEV), bi.to(DEV)), lab.to(DEV)).backward()
+        opt.step()
+        opt.zero_grad()
+        ref_opt.zero_grad()
+        ref_loss.compute_loss(fn(ref_sd, bu, bi), lab).backward()
+        ref_opt.step()
+    for k, v in m.state_dict().items():
+        close(v.cpu(), ref_sd[k].detach(), what=f'{k} after 3 steps', rtol=1e-4, atol=1e-6, norm_rtol=1e-3)   # Adam: rounding of small gradients -> fractions of lr
+
+
+def test_mf_user_bias_raises_like_the_reference():
+    import sibrar_amd as S
+    m = S.SGDMatrixFactorization(U, I, 8, use_user_bias=True).to(DEV)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, dtype=torch.long, device=DEV), torch.zeros(4, 3, dtype=torch.long, device=DEV))
+
+
 @pytest.mark.parametrize('user_kind,loss_name,B', [('lookup', 'bpr', 6), ('entity', 'ssm_uniform', 6), ('linear', 'bce', 6),
                                                    ('entity', 'bpr', 300)])
 def test_fused_step_matches_autograd_path(user_kind, loss_name, B):
