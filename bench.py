@@ -153,7 +153,33 @@ def gemm_table(timings, steps):
     return sorted(rows, key=lambda r: -r['ms_per_step'])
 
 
-def dominant_gemm(timings, steps):
+# GEMM signature of the c2 step at B = 8192 -> (kernel template, grid threads) of its dispatches in the rocprofv3 PMC passes
+# (profiles/r01_bench_hbm_traffic.csv: FETCH_SIZE / WRITE_SIZE collected in their own runs, gfx950 correction applied by
+# tools/make_profiles.py). PMC counters cannot be read inside this process; `traffic` quotes that committed measurement.
+PMC_ROWS = {('TN', 128, 768): ('void gemm_ring_kernel<1, true, true, 2>', 196608),
+            ('TN', 128, 128): ('void gemm_ring_kernel<1, true, true, 2>', 131072),
+            ('NT', 128, 768): ('void gemm_ring_kernel<1, false, false, 2>', 182272),
+            ('NN', 128, 128): ('void gemm_ring_kernel<2, false, true, 2>', 131072),
+            ('NT', 128, 128): ('void gemm_ring_kernel<2, false, false, 2>', 131072)}
+
+
+def pmc_traffic(mode, M, N, K, batch):
+    """HBM bytes per launch of a GEMM signature from the committed PMC summary (None when the run is not the profiled shape)."""
+    if batch != 8192:
+        return None
+    key = {0: ('NT', N, K), 1: ('NN', N, K), 2: ('TN', M, N)}[mode]
+    row = PMC_ROWS.get(key)
+    path = os.path.join(ROOT, 'profiles', 'r01_bench_hbm_traffic.csv')
+    if row is None or not os.path.exists(path):
+        return None
+    import csv
+    for r in csv.reader(l for l in open(path) if not l.startswith('#')):
+        if r[0] == row[0] and r[1] == str(row[1]):
+            return float(r[5]) * 1e6
+    return None
+
+
+def dominant_gemm(timings, steps, batch=None):
     """-> roofline dict of the GEMM signature with the largest total time over the timed steps."""
     best = None
     for key, ts in timings.items():
@@ -168,8 +194,11 @@ def dominant_gemm(timings, steps):
     avg_ms = tot / len(ts)
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
+    traffic = pmc_traffic(mode, M, N, K, batch)
     return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': None,
+            'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': traffic,
+            'traffic_source': None if traffic is None else 'HBM bytes per launch from profiles/r01_bench_hbm_traffic.csv (rocprofv3 '
+                              '--pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
             'kernel': f'fp32 MFMA GEMM (gemm_ring_kernel) mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
                       + (' + split-K slab reduce' if mode == 2 else ''),
             'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps, 4),
@@ -217,7 +246,8 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
             'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
             'sharding': f'items/{world}',
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_MFMA_F16, 4), 'traffic': None, 'kernel': 'score_topk_f16_kernel',
+                         'frac': round(achieved / PEAK_MFMA_F16, 4), 'traffic': None,
+                         'kernel': 'score_topk_f16_wide_kernel' if i16.shape[1] <= 128 else 'score_topk_f16_kernel',
                          'avg_launch_ms': round(avg_ms, 4)}}
 
 
@@ -357,7 +387,7 @@ def main():
             out['config']['replica_param_checksum_spread'] = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
             out['config']['param_checksum'] = [float(c) for c in chk]
             out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
-    roof = dominant_gemm(timings, args.steps) if rank == 0 else None
+    roof = dominant_gemm(timings, args.steps, args.batch_size) if rank == 0 else None
     if roof:
         out['roofline'] = roof
     if not args.no_b256:
