@@ -12,6 +12,7 @@ Reference files followed (relative to /root/reference):
   algorithms/sgd_alg.py:2009-2144        -> ``RefSingleBranchNet``
   algorithms/sgd_alg.py:88-123           -> ``sgd_baseline_logits``
   algorithms/sgd_alg.py:126-200          -> ``mf_logits``
+  algorithms/sgd_alg.py:1399-1614        -> ``feature_mf_forward``
   data/Feature.py:140-162                -> ``RefTable.rows``
 """
 from __future__ import annotations
@@ -389,6 +390,33 @@ def mf_logits(sd, u_idx: torch.Tensor, i_idx: torch.Tensor) -> torch.Tensor:
     if 'global_bias' in sd:
         out = out + sd['global_bias']
     return out
+
+
+def feature_mf_forward(sd, side: str, table: RefTable, u_idx: torch.Tensor, i_idx: torch.Tensor, *, embedding_dim: int,
+                       intermediate_layers=None, aggregate_for_rec: bool = False, temperature: float = 0.1,
+                       embedding_loss_aggregator: str = 'mean', training: bool = True):
+    """ItemFeatureMatrixFactorization (side='item', sgd_alg.py:1399-1505) / UserFeatureMatrixFactorization (side='user',
+    :1508-1614): -> (logits, contrastive loss). The content branch is ``embedding_net`` = FeatureEmbedding(feature,
+    pre_embedding_layers=intermediate_layers, embedding_dim); the scores use the profile embedding or, with
+    ``aggregate_for_rec``, the mean of profile and content; the loss is InfoNCE(profile, content) — for users on [B, 1, D]
+    inputs (one pair per group: identically zero), returned unscaled (lambda_content is never applied)."""
+    idx = i_idx if side == 'item' else u_idx
+    profile = sd[f'{side}_embeddings.weight'][idx]
+    content = feature_embedding(sd, 'embedding_net.', table, idx, embedding_dim, intermediate_layers, 'relu', training)
+    content = content.reshape(*idx.shape, content.shape[-1])
+    mixed = torch.stack([profile, content], dim=0).mean(dim=0) if aggregate_for_rec else profile
+    if side == 'item':
+        u_embed, i_embed = sd['user_embeddings.weight'][u_idx], mixed
+        reg = info_nce(profile, content, temperature, embedding_loss_aggregator)
+    else:
+        u_embed, i_embed = mixed, sd['item_embeddings.weight'][i_idx]
+        reg = info_nce(profile[:, None, :], content[:, None, :], temperature, embedding_loss_aggregator)
+    out = (u_embed[:, None, :] * i_embed).sum(dim=-1)
+    if 'item_bias.weight' in sd:
+        out = out + sd['item_bias.weight'][i_idx].squeeze()
+    if 'global_bias' in sd:
+        out = out + sd['global_bias']
+    return out, reg
 
 
 def init_state_dict(shapes: Dict[str, tuple], seed: int = 42) -> Dict[str, torch.Tensor]:

@@ -10,8 +10,9 @@ from .config import (EmbeddingRegularizationType, FeatureModuleConfig, SingleBra
                      SingleBranchNetConfig, SingleBranchNetEntityConfig)
 from .features import DeviceTable, HostFeature                                              # noqa: F401
 from .polylinear import PolyLinear                                                          # noqa: F401
-from .sbnet import (FeatureEmbedding, SGDBasedRecommenderAlgorithm, SGDBaseline, SGDMatrixFactorization,   # noqa: F401
-                    SingleBranchNet, SingleBranchNetEntity, general_weight_init)
+from .sbnet import (FeatureEmbedding, ItemFeatureMatrixFactorization, SGDBasedRecommenderAlgorithm, SGDBaseline,   # noqa: F401
+                    SGDMatrixFactorization, SingleBranchNet, SingleBranchNetEntity, UserFeatureMatrixFactorization,
+                    general_weight_init)
 from .losses import (InfoNCE, RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy,   # noqa: F401
                      RecSampledSoftmaxLoss, RecommenderSystemLoss, RecommenderSystemLossesEnum)
 from .optim import FlatParameters, FusedOptimizer                                           # noqa: F401
@@ -23,4 +24,5 @@ from .splitdata import SplitDataset, load_split_dataset                         
 from . import ops, parallel, sampling                                                       # noqa: F401
 
 # the reference's registry: AlgorithmsEnum.sbnet / .sgdbias / .mf -> class (algorithms/algorithms_utils.py:14,17,36)
-ALGORITHMS = {'sbnet': SingleBranchNet, 'sgdbias': SGDBaseline, 'mf': SGDMatrixFactorization}
+ALGORITHMS = {'sbnet': SingleBranchNet, 'sgdbias': SGDBaseline, 'mf': SGDMatrixFactorization,
+              'ifeatmf': ItemFeatureMatrixFactorization, 'ufeatmf': UserFeatureMatrixFactorization}

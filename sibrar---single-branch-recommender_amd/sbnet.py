@@ -744,3 +744,108 @@ class SGDMatrixFactorization(SGDBasedRecommenderAlgorithm):
     def build_from_conf(conf: dict, dataset):
         return SGDMatrixFactorization(dataset.n_users, dataset.n_items, conf['embedding_dim'], conf['use_user_bias'],
                                       conf['use_item_bias'], conf['use_global_bias'])
+
+
+class _FeatureMatrixFactorization(SGDMatrixFactorization):
+    """Shared body of ItemFeatureMatrixFactorization / UserFeatureMatrixFactorization (algorithms/sgd_alg.py:1399-1614): matrix
+    factorisation whose item (user) embeddings are pulled towards a projection of a content feature by an InfoNCE term. Reuses
+    the path's kernels: FeatureEmbedding front end (gathered-row MFMA GEMM / lookups), InfoNCE forward + gradient, the
+    modality-mean kernel for ``aggregate_for_rec``, the MF scorer. As in the reference, ``get_and_reset_other_loss`` returns the
+    contrastive loss UNSCALED (``lambda_content`` is stored but never applied, sgd_alg.py:1491-1497)."""
+
+    _side = None      # 'item' | 'user'
+
+    def __init__(self, dataset, feature_name: str, aggregate_for_rec: bool = False, lambda_content: float = 0.0001,
+                 temperature: float = 0.1, embedding_loss_aggregator: str = 'mean', intermediate_layers=None,
+                 embedding_dim: int = 100, use_user_bias: bool = False, use_item_bias: bool = False,
+                 use_global_bias: bool = False):
+        super().__init__(dataset.n_users, dataset.n_items, embedding_dim, use_user_bias, use_item_bias, use_global_bias)
+        from .losses import InfoNCE
+        self.feature_name = feature_name
+        self.aggregate_for_rec = aggregate_for_rec
+        self.lambda_content = lambda_content
+        features = dataset.item_features if self._side == 'item' else dataset.user_features
+        self.embedding_net = FeatureEmbedding(feature=features[feature_name], pre_embedding_layers=intermediate_layers,
+                                              embedding_dim=embedding_dim)
+        self.emb_loss_fn = InfoNCE(temperature, embedding_loss_aggregator)
+        self.emb_loss = 0.
+
+    @staticmethod
+    def _mean2(a, b):
+        """torch.stack([a, b]).mean(0) through the modality-mean kernel."""
+        D = a.shape[-1]
+        e = torch.stack([a.reshape(-1, D), b.reshape(-1, D)], dim=1)
+        return ops.AggregateFn.apply(e, 0).view(a.shape)
+
+    def compute_reg_losses(self, profile_embs, content_embs):
+        self.emb_loss = self.emb_loss_fn(profile_embs, content_embs)
+
+    def get_and_reset_other_loss(self) -> Dict:
+        emb_loss = self.emb_loss
+        self.emb_loss = 0
+        return {'reg_loss': emb_loss}
+
+
+class ItemFeatureMatrixFactorization(_FeatureMatrixFactorization):
+    """algorithms/sgd_alg.py:1399-1505."""
+    _side = 'item'
+
+    def forward(self, u_idxs, i_idxs):
+        u_repr = self.get_user_representations(u_idxs)
+        i_repr = self.get_item_representations(i_idxs)
+        dots = self.combine_user_item_representations(u_repr, i_repr)
+        self.compute_reg_losses(i_repr[0], i_repr[1])
+        return dots
+
+    def get_item_representations(self, i_idxs):
+        profile = ops.LookupFn.apply(self.item_embeddings.weight, i_idxs)
+        content = self.embedding_net(i_idxs)
+        if self.use_item_bias:
+            return profile, content, ops.LookupFn.apply(self.item_bias.weight, i_idxs).squeeze()
+        return profile, content
+
+    def combine_user_item_representations(self, u_repr, i_repr):
+        i_embed = self._mean2(i_repr[0], i_repr[1]) if self.aggregate_for_rec else i_repr[0]
+        if self.use_item_bias:
+            return super().combine_user_item_representations(u_repr, (i_embed, i_repr[-1]))
+        return super().combine_user_item_representations(u_repr, i_embed)
+
+    @staticmethod
+    def build_from_conf(conf: dict, dataset):
+        return ItemFeatureMatrixFactorization(dataset, conf['feature_name'], conf['aggregate_for_rec'], conf['lambda_content'],
+                                              conf['temperature'], conf['embedding_loss_aggregator'], conf['intermediate_layers'],
+                                              conf['embedding_dim'], conf['use_user_bias'], conf['use_item_bias'],
+                                              conf['use_global_bias'])
+
+
+class UserFeatureMatrixFactorization(_FeatureMatrixFactorization):
+    """algorithms/sgd_alg.py:1508-1614. The reference feeds [B, 1, D] to InfoNCE ("blow up first dimension"): every group holds
+    one pair, so the contrastive loss is identically zero — reproduced as is."""
+    _side = 'user'
+
+    def forward(self, u_idxs, i_idxs):
+        u_repr = self.get_user_representations(u_idxs)
+        i_repr = self.get_item_representations(i_idxs)
+        dots = self.combine_user_item_representations(u_repr, i_repr)
+        self.compute_reg_losses(u_repr[0][:, None, :], u_repr[1][:, None, :])
+        return dots
+
+    def get_user_representations(self, u_idxs):
+        profile = ops.LookupFn.apply(self.user_embeddings.weight, u_idxs)
+        content = self.embedding_net(u_idxs).squeeze(dim=1)
+        if self.use_user_bias:
+            return profile, content, ops.LookupFn.apply(self.user_bias.weight, u_idxs).squeeze()
+        return profile, content
+
+    def combine_user_item_representations(self, u_repr, i_repr):
+        u_embed = self._mean2(u_repr[0], u_repr[1]) if self.aggregate_for_rec else u_repr[0]
+        if self.use_user_bias:
+            return super().combine_user_item_representations((u_embed, u_repr[-1]), i_repr)
+        return super().combine_user_item_representations(u_embed, i_repr)
+
+    @staticmethod
+    def build_from_conf(conf: dict, dataset):
+        return UserFeatureMatrixFactorization(dataset, conf['feature_name'], conf['aggregate_for_rec'], conf['lambda_content'],
+                                              conf['temperature'], conf['embedding_loss_aggregator'], conf['intermediate_layers'],
+                                              conf['embedding_dim'], conf['use_user_bias'], conf['use_item_bias'],
+                                              conf['use_global_bias'])

@@ -19,7 +19,8 @@ sys.path.insert(0, HERE)
 import make_golden as G  # noqa: E402  (installs the import placeholders, asserts PYTHONHASHSEED=0)
 
 import torch  # noqa: E402
-from algorithms.sgd_alg import SGDMatrixFactorization, SGDBaseline  # noqa: E402
+from algorithms.sgd_alg import (SGDMatrixFactorization, SGDBaseline, ItemFeatureMatrixFactorization,  # noqa: E402
+                                UserFeatureMatrixFactorization)
 from train.rec_losses import RecBayesianPersonalizedRankingLoss  # noqa: E402
 
 U, I = G.U, G.I
@@ -64,6 +65,47 @@ for ub, ib, gb in ((False, False, False), (False, True, True), (False, True, Fal
     meta['cases'].append({'name': name, 'use_user_bias': ub, 'use_item_bias': ib, 'use_global_bias': gb, 'embedding_dim': 8})
 torch.manual_seed(15)
 record('baseline', SGDBaseline(U, I))
+
+# hybrid factorisation models (sgd_alg.py:1399-1614) on the shared world: item text (dense 768-like vector), item genres (tags),
+# user gender (categorical)
+arrays.update(G.world_arrays())
+ds = G.make_dataset()
+
+
+def record_hybrid(name, m):
+    arrays.update(G.sd2n(m.state_dict(), f'{name}/sd/'))
+    m.train()
+    logits = m(u, i)
+    reg = m.get_and_reset_other_loss()['reg_loss']
+    loss = loss_fn.compute_loss(logits, labels) + reg
+    loss.backward()
+    arrays[f'{name}/logits'], arrays[f'{name}/loss'] = G.t2n(logits), G.t2n(loss)
+    arrays[f'{name}/reg_loss'] = G.t2n(torch.as_tensor(reg, dtype=torch.float32).reshape(-1))
+    for p_name, p in m.named_parameters():
+        arrays[f'{name}/grad/{p_name}'] = G.t2n(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+    m.eval()
+    with torch.no_grad():
+        ir = m.get_item_representations(torch.arange(I))
+        arrays[f'{name}/scores_all'] = G.t2n(m.combine_user_item_representations(m.get_user_representations(u), ir))
+
+
+hybrids = [
+    ('ifmf_text', ItemFeatureMatrixFactorization, dict(feature_name='text', aggregate_for_rec=False, temperature=0.5,
+                                                      intermediate_layers=[10], embedding_dim=8)),
+    ('ifmf_text_agg_bias', ItemFeatureMatrixFactorization, dict(feature_name='text', aggregate_for_rec=True, temperature=0.1,
+                                                               embedding_loss_aggregator='sum', intermediate_layers=None,
+                                                               embedding_dim=8, use_item_bias=True, use_global_bias=True)),
+    ('ifmf_genres', ItemFeatureMatrixFactorization, dict(feature_name='genres', aggregate_for_rec=True, temperature=1.0,
+                                                        intermediate_layers=None, embedding_dim=8)),
+    ('ufmf_gender', UserFeatureMatrixFactorization, dict(feature_name='gender', aggregate_for_rec=True, temperature=0.5,
+                                                        intermediate_layers=None, embedding_dim=8)),
+    ('ufmf_gender_plain', UserFeatureMatrixFactorization, dict(feature_name='gender', aggregate_for_rec=False, temperature=0.5,
+                                                              intermediate_layers=None, embedding_dim=8, use_item_bias=True)),
+]
+for name, cls, kw in hybrids:
+    torch.manual_seed(16)
+    record_hybrid(name, cls(ds, **kw))
+    meta['cases'].append({'name': name, 'class': cls.__name__, 'kwargs': kw})
 np.savez_compressed(os.path.join(HERE, 'g14_sibling_models.npz'), **arrays)
 json.dump(meta, open(os.path.join(HERE, 'g14_sibling_models.json'), 'w'), indent=1)
-print(sorted(arrays)[:12], len(arrays))
+print(len(arrays), [c['name'] for c in meta['cases']])

@@ -248,8 +248,40 @@ def _g14_cases():
     return json.load(open(here))['cases']
 
 
+@pytest.mark.parametrize('case', [c for c in _g14_cases() if 'class' in c], ids=lambda c: c['name'])
+def test_g14_hybrid_factorisation_models_on_hip_kernels(case):
+    """ItemFeature / UserFeatureMatrixFactorization of the product (lookups, FeatureEmbedding front end, InfoNCE kernels, the
+    modality-mean kernel, MF scorer + bias kernels) == the real reference: logits, contrastive loss, total loss, every gradient,
+    evaluation scores through get_*_representations + combine."""
+    import sibrar_amd as S
+    z = load('g14_sibling_models')
+    name = case['name']
+    ds = host_dataset(world(z))
+    m = getattr(S, case['class'])(ds, **case['kwargs'])
+    sd = state_dict(z, f'{name}/sd/')
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    u, i, labels = (torch.from_numpy(z[k]).to(DEV) for k in ('u', 'i', 'labels'))
+    logits = m(u, i)
+    reg = m.get_and_reset_other_loss()['reg_loss']
+    close(logits.detach().cpu(), z[f'{name}/logits'], what='logits', **TOL)
+    close(torch.as_tensor(reg).detach().float().cpu().reshape(-1), z[f'{name}/reg_loss'], what='reg loss', **TOL)
+    loss = _loss('bpr').compute_loss(logits, labels) + reg
+    close(loss.detach().cpu().reshape(()), z[f'{name}/loss'], what='loss', **TOL)
+    loss.backward()
+    for k, p in m.named_parameters():
+        g = p.grad.cpu() if p.grad is not None else torch.zeros(tuple(p.shape))
+        close(g, z[f'{name}/grad/{k}'], what=f'grad {k}', rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        ir = m.get_item_representations(torch.arange(I, device=DEV))
+        scores = m.combine_user_item_representations(m.get_user_representations(u), ir)
+    close(scores.cpu(), z[f'{name}/scores_all'], what='all-pairs scores', **TOL)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', _g14_cases() + [{'name': 'baseline'}], ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', [c for c in _g14_cases() if 'class' not in c] + [{'name': 'baseline'}], ids=lambda c: c['name'])
 def test_g14_sibling_models_on_hip_kernels(case):
     """SGDMatrixFactorization / SGDBaseline of the product (lookups, per-slot dot / all-pairs MFMA GEMM, bias kernels and their
     hand-written backward) == the real reference: train-mode logits, BPR loss, every gradient, evaluation scores through
