@@ -89,6 +89,12 @@ int sbr_resolve_rows(const long* idx, int k, const int* slots, int n, int n_seg,
 int sbr_csr_contains(const long* indptr, const int* indices, const long* rows, const long* cols, long n, unsigned char* out,
                      void* stream);
 
+/* dense interaction vectors of a batch of entities — InteractionRecDataset._get_interaction_vectors, data/dataset.py:306-319
+ * (matrix[indices].toarray()), as consumed by DropoutNet's preference networks (algorithms/sgd_alg.py:1693-1725):
+ * out[j, 0..dim) = CSR row ent[j] (data NULL: ones), all zeros for ent[j] < 0 (dropped preferences). */
+int sbr_csr_rows_to_dense(const long* indptr, const int* indices, const float* data, const long* ent, long n, int dim, float* out,
+                          long ldo, void* stream);
+
 /* nn.Embedding forward — algorithms/sgd_alg.py:1331,1386: out[oi(j), :] = W[rows[j], :] */
 int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx, long n, int D,
                     void* stream);

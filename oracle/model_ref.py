@@ -13,6 +13,7 @@ Reference files followed (relative to /root/reference):
   algorithms/sgd_alg.py:88-123           -> ``sgd_baseline_logits``
   algorithms/sgd_alg.py:126-200          -> ``mf_logits``
   algorithms/sgd_alg.py:1399-1614        -> ``feature_mf_forward``
+  algorithms/sgd_alg.py:1617-1762        -> ``dropoutnet_entity`` / ``dropoutnet_forward``
   data/Feature.py:140-162                -> ``RefTable.rows``
 """
 from __future__ import annotations
@@ -417,6 +418,44 @@ def feature_mf_forward(sd, side: str, table: RefTable, u_idx: torch.Tensor, i_id
     if 'global_bias' in sd:
         out = out + sd['global_bias']
     return out, reg
+
+
+def dropoutnet_entity(sd, prefix: str, ecfg: dict, tables: Dict[str, RefTable], idx: torch.Tensor, preferences: torch.Tensor,
+                      shared_dim: int, training: bool) -> torch.Tensor:
+    """DropoutNetEntity.forward (sgd_alg.py:1645-1655): pref_net(preferences) (PolyLinear defaults: ReLU between layers AND on the
+    output), content modules, concat [*content, pref], net (PolyLinear with the entity's activation, ReLU on the output)."""
+    pl = [preferences.shape[-1]] + list(ecfg['preference_layers'])
+    pref = poly_linear(preferences.reshape(-1, pl[0]), sd, prefix + 'pref_net.', pl, 'relu', 'relu', 0, training)
+    cont = []
+    for j, f in enumerate(ecfg['features']):
+        c = feature_embedding(sd, f'{prefix}cont_modules.{j}.', tables[f['feature_name']], idx, f.get('embedding_dim'),
+                              f.get('pre_embedding_layers'), f.get('activation_fn', 'relu'), training)
+        cont.append(c.reshape(-1, c.shape[-1]))
+    x = torch.cat([*cont, pref], dim=-1)
+    shape = [x.shape[-1]] + list(ecfg['common_hidden_layers']) + [shared_dim]
+    y = poly_linear(x, sd, prefix + 'net.', shape, ecfg.get('activation_fn', 'relu'), 'relu', 0, training)
+    return y.reshape(*idx.shape, shared_dim)
+
+
+def dropoutnet_forward(sd, cfg: dict, user_tables, item_tables, inter, inter_t, u_idx: torch.Tensor, i_idx: torch.Tensor,
+                       user_strategy=None, item_strategy=None, training: bool = True) -> torch.Tensor:
+    """DropoutNet.forward (sgd_alg.py:1689-1757). ``inter`` / ``inter_t``: user x item and item x user CSR training matrices
+    (dataset.get_{user,item}_interaction_vectors = matrix[idx].toarray(), data/dataset.py:306-319). strategies: 1 = Normal,
+    2 = NoPreference (zero preference vector), one per user and one per ROW of ``i_idx``; None = all Normal (evaluation)."""
+    def prefs(idx, matrix, strategy):
+        flat = idx.reshape(-1).numpy()
+        dense = torch.from_numpy(np.asarray(matrix[flat].toarray())).float().reshape(*idx.shape, matrix.shape[1])
+        if strategy is not None:
+            drop = torch.from_numpy(np.asarray(strategy) != 1)
+            dense[drop] = 0.
+        return dense
+    u = dropoutnet_entity(sd, 'user_net.', cfg['user'], user_tables, u_idx, prefs(u_idx, inter, user_strategy),
+                          cfg['shared_common_dim'], training)
+    i = dropoutnet_entity(sd, 'item_net.', cfg['item'], item_tables, i_idx, prefs(i_idx, inter_t, item_strategy),
+                          cfg['shared_common_dim'], training)
+    if i.ndim == 2:
+        return torch.einsum('be,ce->bc', u, i)
+    return torch.einsum('be,bce->bc', u, i)
 
 
 def init_state_dict(shapes: Dict[str, tuple], seed: int = 42) -> Dict[str, torch.Tensor]:

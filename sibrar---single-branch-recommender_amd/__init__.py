@@ -6,13 +6,15 @@ Hand-written HIP kernels behind a C ABI (include/sibrar_hip.h, csrc/), driven th
 ``importlib.import_module('sibrar---single-branch-recommender_amd')``.
 """
 from ._lib import SibrarHipError, lib, LIB_PATH                                            # noqa: F401
-from .config import (EmbeddingRegularizationType, FeatureModuleConfig, SingleBranchFeatureConfig,   # noqa: F401
+from .config import (DropoutNetConfig, DropoutNetEntityConfig, DropoutNetSamplingStrategy,   # noqa: F401
+                     EmbeddingRegularizationType, FeatureModuleConfig, SingleBranchFeatureConfig,
                      SingleBranchNetConfig, SingleBranchNetEntityConfig)
 from .features import DeviceTable, HostFeature                                              # noqa: F401
 from .polylinear import PolyLinear                                                          # noqa: F401
 from .sbnet import (FeatureEmbedding, ItemFeatureMatrixFactorization, SGDBasedRecommenderAlgorithm, SGDBaseline,   # noqa: F401
                     SGDMatrixFactorization, SingleBranchNet, SingleBranchNetEntity, UserFeatureMatrixFactorization,
                     general_weight_init)
+from .dropoutnet import DropoutNet, DropoutNetEntity                                      # noqa: F401
 from .losses import (InfoNCE, RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy,   # noqa: F401
                      RecSampledSoftmaxLoss, RecommenderSystemLoss, RecommenderSystemLossesEnum)
 from .optim import FlatParameters, FusedOptimizer                                           # noqa: F401
@@ -25,4 +27,4 @@ from . import ops, parallel, sampling                                           
 
 # the reference's registry: AlgorithmsEnum.sbnet / .sgdbias / .mf -> class (algorithms/algorithms_utils.py:14,17,36)
 ALGORITHMS = {'sbnet': SingleBranchNet, 'sgdbias': SGDBaseline, 'mf': SGDMatrixFactorization,
-              'ifeatmf': ItemFeatureMatrixFactorization, 'ufeatmf': UserFeatureMatrixFactorization}
+              'ifeatmf': ItemFeatureMatrixFactorization, 'ufeatmf': UserFeatureMatrixFactorization, 'dropoutnet': DropoutNet}

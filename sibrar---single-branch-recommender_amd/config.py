@@ -148,3 +148,51 @@ def coerce_net_config(c) -> SingleBranchNetConfig:
     if isinstance(c, dict):
         return SingleBranchNetConfig.from_dict(c)
     return SingleBranchNetConfig(coerce_side_config(c.user), coerce_side_config(c.item), c.shared_common_dim)
+
+
+# ---- DropoutNet (data/module_config_classes.py:10-42) ---------------------------------------------------------------------------
+class DropoutNetSamplingStrategy(Enum):
+    Normal = 1            # the reference uses enum.auto(): 1, 2
+    NoPreference = 2
+
+    @classmethod
+    def list(cls):
+        return [c.value for c in cls]
+
+
+@dataclass
+class DropoutNetEntityConfig:
+    features: List[FeatureModuleConfig]
+    preference_layers: List[int]          # number of items / users is prepended automatically
+    common_hidden_layers: List[int]       # content + preference dim in front, shared common dim behind
+    activation_fn: str = 'relu'
+
+    @classmethod
+    def from_dict(cls, d: dict):
+        d = dict(d)
+        d['features'] = [f if isinstance(f, FeatureModuleConfig) else FeatureModuleConfig.from_dict(f) for f in d.get('features', [])]
+        return _from_dict(cls, d)
+
+    def to_dict(self):
+        return {'features': [f.to_dict() for f in self.features], 'preference_layers': self.preference_layers,
+                'common_hidden_layers': self.common_hidden_layers, 'activation_fn': self.activation_fn}
+
+
+@dataclass
+class DropoutNetConfig:
+    user: DropoutNetEntityConfig
+    item: DropoutNetEntityConfig
+    shared_common_dim: int
+    sampling_seed: int = 42
+
+    @classmethod
+    def from_dict(cls, d: dict):
+        d = dict(d)
+        for side in ('user', 'item'):
+            if side in d and not isinstance(d[side], DropoutNetEntityConfig):
+                d[side] = DropoutNetEntityConfig.from_dict(d[side])
+        return _from_dict(cls, d)
+
+    def to_dict(self):
+        return {'user': self.user.to_dict(), 'item': self.item.to_dict(), 'shared_common_dim': self.shared_common_dim,
+                'sampling_seed': self.sampling_seed}

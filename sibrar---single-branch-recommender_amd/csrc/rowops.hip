@@ -833,6 +833,31 @@ extern "C" int sbr_bias_score_fwd(const float* user_bias, const float* item_bias
   return SBR_OK;
 }
 
+// Dense interaction vectors of a batch of entities (InteractionRecDataset._get_interaction_vectors, data/dataset.py:306-319:
+// ``matrix[indices].toarray()``) for the models that consume them densely (DropoutNet's preference network, sgd_alg.py:1693-1725):
+// out[j, :] = row ent[j] of the CSR matrix, or all zeros when ent[j] < 0 (an entity whose preferences are dropped).
+__global__ void csr_rows_to_dense_kernel(const long* __restrict__ indptr, const int* __restrict__ indices,
+                                         const float* __restrict__ data, const long* __restrict__ ent, float* __restrict__ out,
+                                         long ldo, int dim) {
+  const long j = blockIdx.x;
+  float* o = out + j * ldo;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) o[c] = 0.f;
+  __syncthreads();
+  const long e = ent[j];
+  if (e < 0) return;
+  for (long p = indptr[e] + threadIdx.x; p < indptr[e + 1]; p += blockDim.x) o[indices[p]] = data ? data[p] : 1.f;
+}
+
+extern "C" int sbr_csr_rows_to_dense(const long* indptr, const int* indices, const float* data, const long* ent, long n, int dim,
+                                     float* out, long ldo, void* stream) {
+  if (n == 0 || dim == 0) return SBR_OK;
+  SBR_REQUIRE(indptr && indices && ent && out, "sbr_csr_rows_to_dense: null operand");
+  SBR_REQUIRE(ldo >= dim, "sbr_csr_rows_to_dense: row stride %ld < %d columns", ldo, dim);
+  csr_rows_to_dense_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(indptr, indices, data, ent, out, ldo, dim);
+  SBR_CHECK_LAUNCH("sbr_csr_rows_to_dense");
+  return SBR_OK;
+}
+
 // Bias terms of the factorisation models (SGDMatrixFactorization.combine, sgd_alg.py:186-194; SGDBaseline, :110-119), forward
 // and backward: out[b, n] = base[b, n] + user_bias[u[b]] + item_bias[i[b, n]] + global_bias, every term optional. u == null:
 // row b itself; i == null: column n itself (all-pairs scoring against an already gathered bias vector).

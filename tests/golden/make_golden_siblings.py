@@ -109,3 +109,62 @@ for name, cls, kw in hybrids:
 np.savez_compressed(os.path.join(HERE, 'g14_sibling_models.npz'), **arrays)
 json.dump(meta, open(os.path.join(HERE, 'g14_sibling_models.json'), 'w'), indent=1)
 print(len(arrays), [c['name'] for c in meta['cases']])
+
+
+# ---- DropoutNet (sgd_alg.py:1617-1762) on the shared world ----------------------------------------------------------------------
+def g15_dropoutnet():
+    from algorithms.sgd_alg import DropoutNet
+    from data.dataset import InteractionRecDataset
+    from data.module_config_classes import DropoutNetConfig, DropoutNetEntityConfig, FeatureModuleConfig
+    out, cases = dict(G.world_arrays()), []
+    ds2 = G.make_dataset()
+    ds2._get_numpy_array = InteractionRecDataset._get_numpy_array
+    ds2.get_user_interaction_vectors = lambda idx: InteractionRecDataset._get_interaction_vectors(ds2, 'user', idx)
+    ds2.get_item_interaction_vectors = lambda idx: InteractionRecDataset._get_interaction_vectors(ds2, 'item', idx)
+    out['u'], out['i'], out['labels'] = G.t2n(u), G.t2n(i), G.t2n(labels)
+    confs = {
+        'dn_small': dict(user=dict(features=[dict(feature_name='gender', embedding_dim=4)], preference_layers=[12, 6],
+                                   common_hidden_layers=[10], activation_fn='relu'),
+                         item=dict(features=[dict(feature_name='text', embedding_dim=5, pre_embedding_layers=[7]),
+                                             dict(feature_name='genres', embedding_dim=4)],
+                                   preference_layers=[9], common_hidden_layers=[], activation_fn='tanh'),
+                         shared_common_dim=8, sampling_seed=42),
+        'dn_nofeat': dict(user=dict(features=[], preference_layers=[6], common_hidden_layers=[], activation_fn='relu'),
+                          item=dict(features=[dict(feature_name='audio', embedding_dim=6)], preference_layers=[5, 5],
+                                    common_hidden_layers=[9, 7], activation_fn='relu'),
+                          shared_common_dim=6, sampling_seed=7),
+    }
+    for name, c in confs.items():
+        def ent(d):
+            return DropoutNetEntityConfig(features=[FeatureModuleConfig(**f) for f in d['features']],
+                                          preference_layers=d['preference_layers'], common_hidden_layers=d['common_hidden_layers'],
+                                          activation_fn=d['activation_fn'])
+        cfg = DropoutNetConfig(user=ent(c['user']), item=ent(c['item']), shared_common_dim=c['shared_common_dim'],
+                               sampling_seed=c['sampling_seed'])
+        if not hasattr(cfg, 'to_dict'):
+            type(cfg).to_dict = lambda self: {}
+        torch.manual_seed(17)
+        m = DropoutNet(cfg, ds2)
+        out.update(G.sd2n(m.state_dict(), f'{name}/sd/'))
+        # the strategies the model is about to draw (user first, then one per row of the item index matrix)
+        probe = np.random.default_rng(c['sampling_seed'])
+        out[f'{name}/user_strategy'] = probe.choice([1, 2], size=len(u), replace=True)
+        out[f'{name}/item_strategy'] = probe.choice([1, 2], size=len(i), replace=True)
+        m.train()
+        logits = m(u, i)
+        loss = loss_fn.compute_loss(logits, labels)
+        loss.backward()
+        out[f'{name}/logits'], out[f'{name}/loss'] = G.t2n(logits), G.t2n(loss)
+        for p_name, p in m.named_parameters():
+            out[f'{name}/grad/{p_name}'] = G.t2n(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+        m.eval()
+        with torch.no_grad():
+            ir = m.get_item_representations(torch.arange(I))
+            out[f'{name}/scores_all'] = G.t2n(m.combine_user_item_representations(m.get_user_representations(u), ir))
+        cases.append({'name': name, 'config': c})
+    np.savez_compressed(os.path.join(HERE, 'g15_dropoutnet.npz'), **out)
+    json.dump({'cases': cases}, open(os.path.join(HERE, 'g15_dropoutnet.json'), 'w'), indent=1)
+    print('g15', len(out), [c['name'] for c in cases], {k: out[k].tolist() for k in out if k.endswith('strategy')})
+
+
+g15_dropoutnet()

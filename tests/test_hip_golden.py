@@ -241,6 +241,41 @@ def test_g11_sgd_baseline():
     close(m(u, i).detach().cpu(), z['logits'], what='logits(train)', **TOL)
 
 
+def _g15_cases():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g15_dropoutnet.json')))['cases']
+
+
+@pytest.mark.parametrize('case', _g15_cases(), ids=lambda c: c['name'])
+def test_g15_dropoutnet_on_hip_kernels(case):
+    """DropoutNet of the product (device-side dense preference vectors, PolyLinear MFMA GEMMs, FeatureEmbedding content modules,
+    scorers) == the real reference: the preference-dropout draws, train-mode logits, BPR loss, every gradient, evaluation
+    scores; config dictionaries parse through DropoutNetConfig.from_dict."""
+    import sibrar_amd as S
+    z = load('g15_dropoutnet')
+    name = case['name']
+    m = S.DropoutNet.build_from_conf(case['config'], host_dataset(world(z)))
+    sd = state_dict(z, f'{name}/sd/')
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    u, i, labels = (torch.from_numpy(z[k]).to(DEV) for k in ('u', 'i', 'labels'))
+    logits = m(u, i)                                            # draws its own strategies: must be the reference's stream
+    close(logits.detach().cpu(), z[f'{name}/logits'], what='logits', **TOL)
+    loss = _loss('bpr').compute_loss(logits, labels)
+    close(loss.detach().cpu(), z[f'{name}/loss'], what='loss', **TOL)
+    loss.backward()
+    for k, p in m.named_parameters():
+        g = p.grad.cpu() if p.grad is not None else torch.zeros(tuple(p.shape))
+        close(g, z[f'{name}/grad/{k}'], what=f'grad {k}', rtol=1e-4, atol=1e-6, norm_rtol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        ir = m.get_item_representations(torch.arange(I, device=DEV))
+        scores = m.combine_user_item_representations(m.get_user_representations(u), ir)
+    close(scores.cpu(), z[f'{name}/scores_all'], what='all-pairs scores', **TOL)
+
+
 def _g14_cases():
     import json
     import os
