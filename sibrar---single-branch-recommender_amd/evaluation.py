@@ -137,11 +137,13 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     kmax = max(evaluator._ks)
     with torch.no_grad():
         items = torch.as_tensor(np.asarray(dataset.items_in_split)).to(device)
-        i_repr = alg.get_item_representations(items)                          # once: [I_s, D]
-        kmax = min(kmax, i_repr.shape[0])
+        i_repr = alg.get_item_representations(items)                          # once: [I_s, D] (or a tuple: embeddings, biases, ...)
+        plain = torch.is_tensor(i_repr)       # models whose item side is more than one matrix score through their own combine
+        i_dev = i_repr.device if plain else i_repr[0].device
+        kmax = min(kmax, int(items.shape[0]))
         excl = getattr(dataset, '_excl_dev', None)
-        if excl is None or excl[0].device != i_repr.device:
-            excl = _csr_to_device(dataset.exclude_data, i_repr.device)
+        if excl is None or excl[0].device != i_dev:
+            excl = _csr_to_device(dataset.exclude_data, i_dev)
             try:
                 dataset._excl_dev = excl
             except Exception:
@@ -150,11 +152,12 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
         bs = int(getattr(eval_loader, 'batch_size', 256) or 256)
         if scorer not in ('fp32', 'fp16_fused'):
             raise ValueError(f'unknown scorer {scorer!r}')
-        if scorer == 'fp16_fused' and (kmax > 32 or i_repr.shape[1] not in (64, 128, 256)):
+        if scorer == 'fp16_fused' and (not plain or kmax > 32 or i_repr.shape[1] not in (64, 128, 256)):
             # the fused kernel keeps at most 32 candidates per user on chip and is built for D in {64, 128, 256}: larger
             # cut-offs (the reference's default evaluator asks for top-100) take the exact fp32 GEMM + radix-select path
             import logging
-            logging.info(f'fp16_fused scorer: k={kmax}, D={i_repr.shape[1]} outside the fused kernel, using the fp32 path')
+            logging.info(f'fp16_fused scorer: k={kmax}, item representation {"tuple" if not plain else tuple(i_repr.shape)} outside '
+                         f'the fused kernel, using the fp32 path')
             scorer = 'fp32'
         i16 = ops.cast_f16(i_repr) if scorer == 'fp16_fused' else None
         if user_chunk is not None:
@@ -162,11 +165,11 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
         elif scorer == 'fp16_fused':
             bs = max(bs, 262144)                                    # one launch for up to 256k users (fp16 rows: 64 MB at D = 128)
         else:
-            bs = max(bs, min(16384, max(1, (1 << 31) // max(int(i_repr.shape[0]), 1))))      # <= 8 GiB of fp32 scores per chunk
+            bs = max(bs, min(16384, max(1, (1 << 31) // max(int(items.shape[0]), 1))))      # <= 8 GiB of fp32 scores per chunk
         for s in range(0, len(users), bs):
             u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
             u_repr = alg.get_user_representations(u_idxs)
-            if scorer == 'fp16_fused':
+            if scorer == 'fp16_fused' and torch.is_tensor(u_repr):
                 _, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1])
             else:
                 out = alg.combine_user_item_representations(u_repr, i_repr)

@@ -605,6 +605,54 @@ def test_trainer_fit_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('model', ['mf', 'ifeatmf', 'ufeatmf', 'dropoutnet', 'sgdbias'])
+def test_sibling_models_train_and_evaluate_through_trainer(model, tmp_path):
+    """The sibling models of SURVEY 8(f).4 through the same Trainer / loader / evaluation as SingleBranchNet (autograd over the
+    HIP kernels, fused optimizer, full-catalogue evaluation via their own combine): the loss falls, NDCG@10 does not get worse
+    than the untrained model's, the best checkpoint reloads."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(400, 150, 9000, item_dense={'text': 24}, item_tags={'genres': (12, 3)}, seed=5, n_negative_samples=5,
+                            holdout_per_user=2)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    common = dict(aggregate_for_rec=True, lambda_content=1e-4, temperature=0.5, embedding_loss_aggregator='mean',
+                  intermediate_layers=[16], embedding_dim=16, use_user_bias=False, use_item_bias=True, use_global_bias=False)
+    confs = {
+        'mf': dict(embedding_dim=16, use_user_bias=False, use_item_bias=True, use_global_bias=True),
+        'ifeatmf': dict(feature_name='text', **common),
+        'ufeatmf': dict(feature_name='user_embedding', **{**common, 'intermediate_layers': None}),
+        'dropoutnet': dict(user=dict(features=[], preference_layers=[32], common_hidden_layers=[]),
+                           item=dict(features=[dict(feature_name='text', embedding_dim=16), dict(feature_name='genres', embedding_dim=8)],
+                                     preference_layers=[32], common_hidden_layers=[32]), shared_common_dim=16),
+        'sgdbias': {},
+    }
+    if model == 'ufeatmf':        # a categorical user feature: the user id itself (what SingleBranchNet adds as 'user_embedding')
+        ds.user_features = dict(getattr(ds, 'user_features', {}) or {})
+        ds.user_features['user_embedding'] = S.HostFeature('user_embedding', 'categorical', np.arange(ds.n_users), n_categories=ds.n_users)
+    net = S.ALGORITHMS[model].build_from_conf(confs[model], ds).to(DEV)
+    loss = S.RecBinaryCrossEntropy(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=5)
+    # DropoutNet ends in a ReLU on both sides (PolyLinear's default output_fn): at lr 1e-2 the output units die within an epoch
+    # (all logits 0, loss ln 2 from then on — the reference's arithmetic does the same), so it trains at 1e-3
+    lr = 1e-3 if model == 'dropoutnet' else 1e-2
+    conf = {'learn': {'lr': lr, 'wd': 1e-6, 'optimizer': 'adamw', 'n_epochs': 3, 'optimizing_metric': 'ndcg@10', 'max_patience': 3},
+            'run_settings': {'device': DEV, 'batch_verbose': False}, 'results_path': str(tmp_path),
+            'eval': S.evaluation._Cfg(top_k=(1, 10, 20)), 'train_eval': None, 'scorer': 'fp32'}
+    train_loader = S.NegativeSamplingDataLoader(ds, batch_size=256, shuffle=True, device=DEV)
+    val_loader = type('L', (), {'dataset': ds.eval_view(), 'batch_size': 128})()
+    tr = S.Trainer(net, train_loader, val_loader, loss, conf)
+    assert tr.fused is None
+    l0 = tr.train()['train/loss']
+    best = tr.fit()
+    l_end = tr.train()['train/loss']
+    train_loader.close()
+    assert l_end < l0, (l0, l_end)
+    assert best['ndcg@10'] > 0 and best['max_optimizing_metric'] == best['ndcg@10'] and 'best_epoch' in best
+    fresh = S.ALGORITHMS[model].build_from_conf(confs[model], ds).to(DEV)
+    fresh.load_model_from_path(str(tmp_path))
+    assert set(fresh.state_dict()) == set(net.state_dict())
+
+
+@pytest.mark.gpu
 def test_split_dataset_trains_and_evaluates():
     """The on-disk fixture (tests/golden/split_random, the reference's directory format) loaded with load_split_dataset drives the
     whole path: SingleBranchNet over a tag + vector + id-embedding item entity and a categorical user feature, loader,
