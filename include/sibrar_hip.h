@@ -215,6 +215,14 @@ int sbr_infonce_gemm_bwd(const float* A, const float* B, long ld, long G, int N,
  * kind 0 = torch.optim.AdamW, 1 = torch.optim.Adam; step is the 1-based step count. */
 int sbr_adam_step(int kind, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                   double wd, long step, void* stream);
+/* The same dense-optimizer semantics for a [n_rows, D] lookup table, deferred row by row (train/trainer.py:62-68 updates every row
+ * every step; a row without gradient can take its zero-gradient updates later, in order, bit-identically). mode 0: bring the rows
+ * named by ids (int64 or int32, optionally through rowmap) up to step - 1 (before the forward pass reads them); mode 1: the same,
+ * then apply `step` with their gradient rows, zero those gradient rows, record the step's scalars in sched[step]; mode 2: flush
+ * every row to `step` (before any other reader). claim, last: int32 [n_rows] zero-initialised; sched: float2 [> step]. */
+int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64, const int* ids32,
+                  const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1, double b2, double eps,
+                  double wd, long step, void* stream);
 int sbr_adagrad_step(float* p, const float* g, float* state_sum, long n, double lr, double eps, double wd, void* stream);
 
 /* ---- full-catalogue evaluation — eval/eval.py:205-222 ------------------------------------------------------------------------

@@ -4,21 +4,113 @@
 // The arithmetic follows torch's single-tensor rules in fp32, in the same operation order.
 #include "common.h"
 
+// One element of one Adam / AdamW step. The dense kernel and the row-wise (deferred) kernels below go through this one inlined
+// function with run-time operands, so that a deferred row replays exactly the instruction sequence the dense kernel would have
+// executed for it (same contractions, same rounding).
+struct AdamHyper { float lr, b1, b2, eps, wd; int decoupled; };
+
+__device__ __forceinline__ void adam_element(float& pe, float ge, float& me, float& ve, const AdamHyper& h, float step_size,
+                                             float bc2_sqrt) {
+  // no fused multiply-add contraction here: left to itself the compiler contracts differently in different callers (mul + add
+  // in the dense kernel, v_pk_fma in the flush kernel), and a deferred row must round exactly like a densely updated one
+#pragma clang fp contract(off)
+  if (h.decoupled) pe *= (1.f - h.lr * h.wd);     // AdamW: p.mul_(1 - lr * wd)
+  else ge += h.wd * pe;                            // Adam: grad = grad.add(p, alpha=wd)
+  me = me + (ge - me) * (1.f - h.b1);              // exp_avg.lerp_(grad, 1 - beta1)
+  ve = ve * h.b2 + (1.f - h.b2) * ge * ge;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const float denom = sqrtf(ve) / bc2_sqrt + h.eps;
+  pe = pe - step_size * (me / denom);
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             long n, float lr, float b1, float b2, float eps, float wd, float step_size, float bc2_sqrt,
-                             int decoupled) {
+                             long n, AdamHyper h, float step_size, float bc2_sqrt) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    float pe = p[e], ge = g[e];
-    if (decoupled) pe *= (1.f - lr * wd);       // AdamW: p.mul_(1 - lr * wd)
-    else ge += wd * pe;                         // Adam: grad = grad.add(p, alpha=wd)
-    const float me = m[e] + (ge - m[e]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float ve = v[e] * b2 + (1.f - b2) * ge * ge;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float denom = sqrtf(ve) / bc2_sqrt + eps;
-    p[e] = pe - step_size * (me / denom);
+    float pe = p[e], me = m[e], ve = v[e];
+    adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
+    p[e] = pe;
     m[e] = me;
     v[e] = ve;
   }
 }
+
+// ---- deferred row-wise Adam for lookup tables --------------------------------------------------------------------------------
+// The reference's dense optimizer (trainer.py:62-68) updates EVERY row of an embedding table EVERY step — rows without a
+// gradient still decay their moments and their weights — which makes the optimizer the largest kernel of the step for large
+// tables (c4: 7.2 GB of state per step). A row that gets no gradient at steps s0+1 .. t-1 can take those updates later, in
+// order, with g = 0: the arithmetic is the same sequence of fp32 operations, so the result is bit-identical to the dense
+// optimizer's. State per table: last[r] = step up to which row r is current; sched[s] = (lr / bc1(s), sqrt(bc2(s))) of every
+// step so far (evaluated on the host in double as for the dense kernel). A step brings the rows its batch READS up to t-1
+// before the forward pass (catch-up), updates the rows that RECEIVED gradient with step t after the backward pass, and a
+// flush replays everything before any other reader (evaluation, state_dict, checkpoints) looks at the table.
+// Duplicate rows in a batch: the first wave to raise claim[r] to the launch's token owns the row.
+__device__ __forceinline__ void adam_replay(float& pe, float& me, float& ve, int s_from, int s_to, const float2* __restrict__ sched,
+                                            const AdamHyper& h, float zero) {
+  for (int s = s_from; s <= s_to; ++s) {
+    const float2 sc = sched[s];
+    adam_element(pe, zero, me, ve, h, sc.x, sc.y);
+  }
+}
+
+// mode 0: catch-up of the rows ids[j] (mapped through rowmap when given) to step t - 1.
+// mode 1: catch-up to t - 1, then step t with the gradient row; the gradient row is zeroed; sched[t] is recorded.
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int D, const long* __restrict__ ids64,
+                                                        const int* __restrict__ ids32, const int* __restrict__ rowmap, long n,
+                                                        int* __restrict__ claim, int* __restrict__ last,
+                                                        float2* __restrict__ sched, int t, AdamHyper h, float step_size,
+                                                        float bc2_sqrt, const float* __restrict__ zero_src, int mode) {
+  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) sched[t] = make_float2(step_size, bc2_sqrt);
+  if (j >= n) return;
+  long id = ids64 ? ids64[j] : (long)ids32[j];
+  const int r = rowmap ? rowmap[id] : (int)id;
+  if (r < 0) return;                                          // id without a row: flagged by the lookup kernel
+  const int token = 2 * t - 1 + mode;
+  int old = 0;
+  if (lane == 0) old = atomicMax(&claim[r], token);
+  old = __shfl(old, 0, 64);
+  if (old >= token) return;                                   // another wave of this launch owns the row
+  const int s0 = last[r];
+  const float zero = zero_src[0];
+  for (int c = lane; c < D; c += 64) {
+    const long e = (long)r * D + c;
+    float pe = p[e], me = m[e], ve = v[e];
+    adam_replay(pe, me, ve, s0 + 1, t - 1, sched, h, zero);
+    if (mode == 1) {
+      adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
+      g[e] = 0.f;
+    }
+    p[e] = pe;
+    m[e] = me;
+    v[e] = ve;
+  }
+  if (lane == 0) last[r] = mode == 1 ? t : t - 1;
+}
+
+// every row of the table up to step t (before another reader looks at the table)
+__global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                              int D, long n_rows, int* __restrict__ last,
+                                                              const float2* __restrict__ sched, int t, AdamHyper h,
+                                                              const float* __restrict__ zero_src) {
+  const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int s0 = last[r];
+  if (s0 >= t) return;
+  const float zero = zero_src[0];
+  for (int c = lane; c < D; c += 64) {
+    const long e = r * D + c;
+    float pe = p[e], me = m[e], ve = v[e];
+    adam_replay(pe, me, ve, s0 + 1, t, sched, h, zero);
+    p[e] = pe;
+    m[e] = me;
+    v[e] = ve;
+  }
+  if (lane == 0) last[r] = t;
+}
+
+__device__ float sbr_adam_zero = 0.f;
 
 __global__ void adagrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s, long n, float lr,
                                float eps, float wd) {
@@ -45,9 +137,44 @@ extern "C" int sbr_adam_step(int kind, float* p, const float* g, float* m, float
   if (n == 0) return SBR_OK;
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  adamw_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)lr, (float)b1, (float)b2, (float)eps, (float)wd,
-                                                             (float)(lr / bc1), (float)sqrt(bc2), kind == 0);
+  const AdamHyper h = {(float)lr, (float)b1, (float)b2, (float)eps, (float)wd, kind == 0};
+  adamw_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
   SBR_CHECK_LAUNCH("sbr_adam_step");
+  return SBR_OK;
+}
+
+// Deferred row-wise Adam / AdamW over one [n_rows, D] lookup table (see adam_rows_kernel). mode 0: bring the rows named by
+// ids (int64 ids64 or int32 ids32, optionally mapped through rowmap) up to step - 1; mode 1: the same, then apply `step` with
+// their gradient rows, zero those gradient rows and record the step's scalars in sched[step]; mode 2: flush all rows to `step`.
+// claim / last: int32 [n_rows], zero-initialised by the caller; sched: float2 [>= step + 1].
+extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64,
+                             const int* ids32, const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1,
+                             double b2, double eps, double wd, long step, void* stream) {
+  SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_rows: unknown kind %d", kind);
+  SBR_REQUIRE(mode >= 0 && mode <= 2, "sbr_adam_rows: unknown mode %d", mode);
+  SBR_REQUIRE(p && m && v && last && sched, "sbr_adam_rows: null operand");
+  SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_rows: step %ld out of range", step);
+  const AdamHyper h = {(float)lr, (float)b1, (float)b2, (float)eps, (float)wd, kind == 0};
+  float* zero = nullptr;
+  if (hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(sbr_adam_zero)) != hipSuccess) {
+    sbr_set_error("sbr_adam_rows: hipGetSymbolAddress failed");
+    return SBR_ERR_HIP;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 2) {
+    if (n_rows == 0) return SBR_OK;
+    adam_rows_flush_kernel<<<sbr_cdiv(n_rows, 4), 256, 0, s>>>(p, m, v, D, n_rows, last, (const float2*)sched, (int)step, h, zero);
+    SBR_CHECK_LAUNCH("sbr_adam_rows (flush)");
+    return SBR_OK;
+  }
+  SBR_REQUIRE(claim && (ids64 || ids32), "sbr_adam_rows: null operand");
+  SBR_REQUIRE(mode == 0 || g, "sbr_adam_rows: the update needs the gradient");
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  const long blocks = n > 0 ? sbr_cdiv(n, 4) : 1;           // mode 1 with no rows still records sched[step]
+  adam_rows_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, D, ids64, ids32, rowmap, n, claim, last, (float2*)sched, (int)step, h,
+                                          (float)(lr / bc1), (float)sqrt(bc2), zero, mode);
+  SBR_CHECK_LAUNCH("sbr_adam_rows");
   return SBR_OK;
 }
 

@@ -322,6 +322,62 @@ class _PlainRun:
         fe.front_backward(ps, self.hidden, self.rows, self.n, self.out, dout, None, grad_out=[_grad_of(p) for p in ps])
 
 
+class DeferredTable:
+    """Deferred row-wise Adam / AdamW for ONE lookup table (``sbr_adam_rows``; csrc/optim.hip explains why the result is
+    bit-identical to the dense optimizer of train/trainer.py:62-68). ``catch_up`` before the forward pass of a step, ``update``
+    after its backward pass, ``flush`` before anybody else reads the table: the model's state_dict, its module-level forward
+    (evaluation, autograd path), a dense optimizer step, ``FusedTrainStep.close``."""
+
+    def __init__(self, opt, param: torch.Tensor, lo: int, hi: int, rowmap: Optional[torch.Tensor]):
+        n_rows, D = param.shape
+        assert param.stride() == (D, 1) and hi - lo == n_rows * D
+        self.opt, self.lo, self.hi, self.n_rows, self.D, self.rowmap = opt, lo, hi, n_rows, D, rowmap
+        fp = opt.fp
+        self.p, self.g = fp.flat[lo:hi], fp.grad[lo:hi]
+        self.m, self.v = opt.m[lo:hi], opt.v[lo:hi]
+        dev = self.p.device
+        self.last = torch.zeros(n_rows, device=dev, dtype=torch.int32)
+        self.claim = torch.zeros(n_rows, device=dev, dtype=torch.int32)
+        self.sched = torch.zeros(4096, 2, device=dev, dtype=torch.float32)
+        self.kind = 0 if opt.name == 'adamw' else 1
+        self.flushed_to = 0          # step up to which EVERY row is known to be current
+        if opt.step_count > 0:       # steps taken densely before this object existed: every row is current
+            self.last.fill_(opt.step_count)
+            self.flushed_to = opt.step_count
+
+    def _call(self, mode: int, ids, step: int):
+        if step >= self.sched.shape[0]:
+            bigger = torch.zeros(2 * max(step, self.sched.shape[0]), 2, device=self.sched.device, dtype=torch.float32)
+            bigger[:self.sched.shape[0]] = self.sched
+            self.sched = bigger
+        ids64 = ids if ids is not None and ids.dtype == torch.int64 else None
+        ids32 = ids if ids is not None and ids.dtype == torch.int32 else None
+        o = self.opt
+        call('sbr_adam_rows', self.kind, mode, ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.n_rows, self.D, ptr(ids64),
+             ptr(ids32), ptr(self.rowmap) if ids64 is not None else None, 0 if ids is None else ids.numel(), ptr(self.claim),
+             ptr(self.last), ptr(self.sched), float(o.lr), 0.9, 0.999, 1e-8, float(o.wd), int(step), ops.stream())
+
+    def catch_up(self, ids: torch.Tensor):
+        """ids: the entity ids (int64, mapped through the table's id map) or table rows (int32) the coming step reads."""
+        if self.opt.step_count > self.flushed_to:
+            self._call(0, ids, self.opt.step_count + 1)
+
+    def update(self, ids: torch.Tensor):
+        """Apply step ``opt.step_count`` (already counted by step_flat) to the rows that received gradient; zeroes those rows."""
+        self._call(1, ids, self.opt.step_count)
+
+    def flush(self):
+        t = self.opt.step_count
+        if t > self.flushed_to:
+            self._call(2, None, t)
+            self.flushed_to = t
+
+    def mark_all_current(self):
+        """A dense optimizer step has just updated every row (FusedOptimizer.step_flat without ``skip``)."""
+        self.last.fill_(self.opt.step_count)
+        self.flushed_to = self.opt.step_count
+
+
 class FusedTrainStep:
     """``use_graph`` (default: on, env ``SBR_GRAPH=0`` turns it off): forward + backward of a step are captured once per
     batch signature into a hipGraph and replayed — one launch instead of ~50. The step is made a pure function of device
@@ -366,6 +422,21 @@ class FusedTrainStep:
             self._sparse = False
         _LIVE.add(self)
         self.opt.zero_grad()
+        # lookup user table updated row by row instead of densely (DeferredTable). Needs to know which rows received
+        # gradient: the batch's users on one GPU, the all-gathered row lists of the sparse exchange in a data-parallel run.
+        self.deferred = None
+        fe = net.user_embedding_module
+        if (isinstance(self.user, _PlainRun) and fe.kind == 'categorical' and self._urange is not None
+                and optimizer.name in ('adamw', 'adam') and optimizer.deferred is None
+                and os.environ.get('SBR_DEFERRED_ADAM', '1') != '0'
+                and (not parallel.is_distributed() or self._sparse is not False)):
+            table = fe.front_params()[0]
+            lo, hi = self._urange
+            if table.dim() == 2 and table.stride() == (table.shape[1], 1) and hi - lo == table.numel():
+                self.deferred = DeferredTable(optimizer, table, lo, hi, fe._table.rowmap)
+                optimizer.deferred = self.deferred
+                self._hooks = [net.register_state_dict_pre_hook(lambda *a, **k: self.flush()),
+                               fe.register_forward_pre_hook(lambda *a, **k: self.flush())]
 
     def draw(self, u_shape, i_shape):
         """Modality draws of one step (user side first, as in SingleBranchNet.forward). May be called from the loader
@@ -556,6 +627,10 @@ class FusedTrainStep:
             out = None
             if self._sparse is None:
                 self._setup_sparse_exchange(int(pb.u_shape[0]))
+                if self._sparse is False and self.deferred is not None:       # dense all-reduce: touched rows unknown
+                    self._drop_deferred()
+            if self.deferred is not None:
+                self.deferred.catch_up(pb.u[:-1])                            # the rows this step's forward pass reads
             if self.use_graph and pb.pi[5] and not ops.KernelTimer.enabled:
                 if self._arena_buf is not self.arena.buf:            # the arena moved: captured addresses are stale
                     self._graphs.clear()
@@ -589,9 +664,30 @@ class FusedTrainStep:
                 out = self._phase2().clone().unbind(0)
             # ---- reduce + update
             self._reduce_rest(pending)
-            self.opt.step_flat()
-            self.opt.fp.grad.zero_()
+            if self.deferred is None:
+                self.opt.step_flat()
+                self.opt.fp.grad.zero_()
+            else:
+                d, g = self.deferred, self.opt.fp.grad
+                self.opt.step_flat(skip=(d.lo, d.hi))
+                d.update(self._touched_rows if self._sparse else pb.u[:-1])   # also re-zeroes the gradient rows it consumed
+                g[:d.lo].zero_()
+                g[d.hi:].zero_()
             return out
+
+    def flush(self):
+        """Bring a row-wise updated table up to date (no-op otherwise). Called automatically before state_dict(), the user
+        module's own forward, a dense optimizer step and close(); call it before reading parameter tensors directly."""
+        if self.deferred is not None:
+            with pin_stream():
+                self.deferred.flush()
+
+    def _drop_deferred(self):
+        self.flush()
+        for h in getattr(self, '_hooks', []):
+            h.remove()
+        self.opt.deferred = None
+        self.deferred = None
 
     # ---- data-parallel gradient exchange, overlapped with the item side's backward -----------------------------------------------
     def _user_range(self):
@@ -646,6 +742,7 @@ class FusedTrainStep:
         D = table.shape[1]
         W = recv.shape[0]
         rows = recv[:, cap * D:].view(torch.int32).reshape(-1)        # [W * cap], rank-major (a copy: the view is strided)
+        self._touched_rows = rows                                     # every row that receives gradient this step
         rows_sorted, perm = torch.sort(rows, stable=True)
         call('sbr_scatter_add_rows_sorted', ptr(recv), D, cap, recv.stride(0), ptr(perm), ptr(rows_sorted), ptr(dW),
              dW.stride(0), W * cap, D, ops.stream())
@@ -673,7 +770,12 @@ class FusedTrainStep:
         self.net.check_index_errors()
 
     def close(self):
-        """Drop the captured graphs (also done at interpreter exit: hipGraph objects must not outlive the HIP runtime)."""
+        """Drop the captured graphs (also done at interpreter exit: hipGraph objects must not outlive the HIP runtime) and bring
+        a row-wise updated table up to date."""
+        try:
+            self.flush()
+        except Exception:
+            pass
         self._graphs.clear()
 
 

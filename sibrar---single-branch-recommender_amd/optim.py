@@ -76,6 +76,7 @@ class FusedOptimizer:
         n, dev = self.fp.total, self.fp.flat.device
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32) if name != 'adagrad' else None
+        self.deferred = None         # engine.DeferredTable of a fused step that updates one lookup table row by row
 
     def _sync_grads(self):
         """Gradients that autograd produced as fresh tensors (instead of accumulating into the flat views) are copied in."""
@@ -90,15 +91,24 @@ class FusedOptimizer:
         self._sync_grads()
         self.step_flat()
 
-    def step_flat(self):
-        """Update from the flat gradient buffer as it is (the fused step writes gradients there directly)."""
+    def step_flat(self, skip=None):
+        """Update from the flat gradient buffer as it is (the fused step writes gradients there directly).
+        ``skip`` = (lo, hi): leave that range of the flat buffers alone — a lookup table whose rows the fused step updates
+        itself, deferred row by row (engine.DeferredTable). A step without ``skip`` first brings such a table up to date."""
+        if skip is None and self.deferred is not None:
+            self.deferred.flush()
         self.step_count += 1
         fp = self.fp
         if self.name == 'adagrad':
             ops.adagrad_step(fp.flat, fp.grad, self.m, self.lr, 1e-10, self.wd)
-        else:
-            ops.adam_step(0 if self.name == 'adamw' else 1, fp.flat, fp.grad, self.m, self.v, self.lr, 0.9, 0.999, 1e-8,
-                          self.wd, self.step_count)
+            return
+        kind = 0 if self.name == 'adamw' else 1
+        for lo, hi in ([(0, fp.total)] if skip is None else [(0, skip[0]), (skip[1], fp.total)]):
+            if hi > lo:
+                ops.adam_step(kind, fp.flat[lo:hi], fp.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, 0.9, 0.999, 1e-8,
+                              self.wd, self.step_count)
+        if skip is None and self.deferred is not None:
+            self.deferred.mark_all_current()           # this step updated the table densely
 
     def zero_grad(self):
         self.fp.zero_grad()

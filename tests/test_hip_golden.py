@@ -530,6 +530,54 @@ def test_data_parallel_step_over_rccl_one_rank(exchange, monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('optimizer', ['adamw', 'adam'])
+def test_fused_step_with_deferred_row_wise_adam_equals_dense_optimizer(optimizer, monkeypatch):
+    """The fused step updates a lookup user table row by row (engine.DeferredTable / sbr_adam_rows: rows without gradient take
+    their zero-gradient steps later, in order; bit-exactness of that replay is pinned on deterministic gradients in
+    tests/test_hip_kernels.py). End to end — 25 steps in which most of 2000 users are touched rarely, duplicates inside batches,
+    a state_dict() flush in the middle — the run agrees with the dense-optimizer run (SBR_DEFERRED_ADAM=0) as closely as two
+    dense runs agree with each other (the table gradients themselves come from float atomics)."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(2000, 200, 9000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
+    cfg = {'shared_common_dim': 32, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [32], 'preference_hidden_layers': [], 'common_modality_dim': 32}}
+    runs = []
+    for deferred in ('0', '1'):
+        monkeypatch.setenv('SBR_DEFERRED_ADAM', deferred)
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+        net.train()
+        opt = S.FusedOptimizer(net, optimizer, lr=1e-2, weight_decay=1e-2)
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+        fused = S.FusedTrainStep(net, loss, opt)
+        assert (fused.deferred is not None) == (deferred == '1')
+        rng = np.random.default_rng(9)
+        losses, mid = [], None
+        for s_ in range(25):
+            u = torch.from_numpy(rng.integers(0, 60 if s_ % 5 == 0 else ds.n_users, size=48))     # some batches hit few users
+            u[1] = u[0]                                                       # a duplicate row inside the batch
+            i = torch.from_numpy(rng.integers(0, ds.n_items, size=(48, 4)))
+            labels = torch.zeros(48, 4, dtype=torch.float64)
+            labels[:, 0] = 1
+            losses.append(torch.stack(fused.step(u, i, labels)).cpu())
+            if s_ == 12:
+                mid = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        fused.close()
+        lo, hi = fused._urange
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+                     opt.m[lo:hi].cpu().clone(), opt.v[lo:hi].cpu().clone(), mid))
+    key = 'user_embedding_module.embedding_layer.weight'
+    close(runs[1][1][key], runs[0][1][key], what='user table', rtol=1e-4, atol=1e-5)
+    close(runs[1][4][key], runs[0][4][key], what='user table at the mid-run flush', rtol=1e-4, atol=1e-5)
+    close(runs[1][2], runs[0][2], what='first moments', rtol=1e-4, atol=1e-6)
+    close(runs[1][3], runs[0][3], what='second moments', rtol=1e-4, atol=1e-8)
+    for s_, (a_, b_) in enumerate(zip(runs[0][0], runs[1][0])):
+        close(b_, a_, what=f'losses step {s_}', rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
 def test_loader_pipeline_equals_inline_steps():
     """Batches prepared ahead by the loader's two producer threads (collate -> FusedTrainStep.prepare with pinned packed
     uploads, device-cached labels, graph replay) train the model exactly like the same batches stepped inline."""

@@ -517,3 +517,61 @@ def test_scatter_add_rows_sorted_is_the_dense_gradient_without_atomics(W, cap, D
     ref.index_add_(0, rows.reshape(-1).long(), grads.reshape(-1, D).double())
     close(outs[0], ref, rtol=1e-5, atol=1e-5, what='sorted scatter')
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('name', ['adamw', 'adam'])
+def test_deferred_row_wise_adam_replay_is_bit_identical(name):
+    """sbr_adam_rows (engine.DeferredTable): a lookup table whose rows take the optimizer steps they missed later, in order, with
+    zero gradient, ends BIT-identical to the dense optimizer (torch.optim semantics, train/trainer.py:62-68) stepping the whole
+    table every time: parameters and both moment buffers, after 40 steps with deterministic gradients in which rows go
+    untouched for long stretches, with duplicate ids in the touched lists, an id map, a flush in the middle, and a dense
+    step (FusedOptimizer.step) interleaved."""
+    import sibrar_amd as S
+    from importlib import import_module
+    engine = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine')
+    R, D = 300, 48
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(R, D, generator=g) * 0.1
+    rowmap = torch.randperm(R, generator=g).to(torch.int32)           # entity id -> table row
+    mods, opts = [], []
+    for _ in range(2):
+        m = torch.nn.Embedding(R, D)
+        with torch.no_grad():
+            m.weight.copy_(w0)
+        m.to(DEV)
+        mods.append(m)
+        opts.append(S.FusedOptimizer(m, name, lr=3e-3, weight_decay=1e-2))
+    d = engine.DeferredTable(opts[1], mods[1].weight, 0, R * D, rowmap.to(DEV))
+    opts[1].deferred = d
+    rng = np.random.default_rng(2)
+    for t in range(40):
+        n = int(rng.integers(1, 12))
+        ids = torch.from_numpy(rng.integers(0, R if t % 7 else 5, size=n))          # entity ids, duplicates likely
+        rows = rowmap[ids].long().unique()
+        grad_rows = torch.randn(len(rows), D, generator=g)
+        if t == 20:                                                               # a dense step in between (autograd path)
+            for o, m in zip(opts, mods):
+                o.zero_grad()
+                m.weight.grad[rows.to(DEV)] = grad_rows.to(DEV)
+                o.step()
+                o.zero_grad()
+            continue
+        # dense reference
+        opts[0].zero_grad()
+        mods[0].weight.grad[rows.to(DEV)] = grad_rows.to(DEV)
+        opts[0].step_flat()
+        # deferred: rows read by the "forward" are brought up to date, gradient rows written, touched rows updated
+        ids_dev = ids.to(DEV)
+        d.catch_up(ids_dev)
+        current = mods[1].weight.detach()[rows.to(DEV)].cpu()
+        assert torch.equal(current, mods[0].weight.detach()[rows.to(DEV)].cpu() * 0 + current)      # (read forces the sync)
+        mods[1].weight.grad[rows.to(DEV)] = grad_rows.to(DEV)
+        opts[1].step_flat(skip=(0, R * D))
+        d.update(ids_dev)
+        assert float(mods[1].weight.grad.abs().max()) == 0.0                       # consumed gradient rows are re-zeroed
+        if t == 11:
+            d.flush()
+            assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
+    d.flush()
+    assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
+    assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
