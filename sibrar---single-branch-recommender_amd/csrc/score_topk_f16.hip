@@ -73,6 +73,42 @@ __device__ __forceinline__ float st_compact(const TopkState& st, int r, int n_an
   return thr;
 }
 
+// Compaction during the stream does not need the survivors sorted: keep the k best of the first n (<= 64, wave-uniform) entries
+// of row r's buffer at positions [0, k), in buffer order, and return the new threshold. The k-th largest score key is found by
+// a bitwise binary search over ballot counts (32 steps of v_cmp + s_bcnt1; ties at that key are resolved on the item half of
+// the composite the same way) — about a sixth of the cycles of the ranking in st_compact, which the final pass still uses.
+__device__ __forceinline__ float st_select(const TopkState& st, int r, int n_any, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_any);
+  lds_u64* b = st.buf + r * st.cap;
+  st_wave_fence();
+  const unsigned long long mine = lane < n ? b[lane] : 0ull;
+  if (n < st.k) return -INFINITY;
+  const unsigned int h = (unsigned int)(mine >> 32);
+  unsigned int T = 0u;                                       // real keys are > 0, empty lanes hold 0
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    T = __popcll(__ballot(h >= trial)) >= st.k ? trial : T;
+  }
+  unsigned long long C = (unsigned long long)T << 32;
+  if (__popcll(__ballot(h >= T)) != st.k) {                  // several entries share the k-th key: smallest item indices stay
+    const int need = st.k - __popcll(__ballot(h > T));
+    const unsigned int l = (unsigned int)mine;
+    unsigned int Lw = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = Lw | (1u << bit);
+      Lw = __popcll(__ballot(h == T && l >= trial)) >= need ? trial : Lw;
+    }
+    C |= (unsigned long long)Lw;
+  }
+  const bool keep = mine >= C;                               // exactly k lanes (composites are unique and non-zero)
+  const unsigned long long kb = __ballot(keep);
+  const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)kb, 0u));
+  st_wave_fence();
+  if (keep) b[pos] = mine;
+  st_wave_fence();
+  return st_key2f(T);
+}
+
 // overflow path of one accumulator register step: some lanes could not append because their row's buffer is full.
 // Compacts those rows (raising their thresholds) and retries until every pending candidate is stored or beaten.
 // thr / cnt are the lane's register copies of its row's threshold and fill count (identical in the 32 lanes that share the
@@ -89,7 +125,7 @@ __device__ __noinline__ RowState st_overflow(TopkState st, float v, bool pending
     const int r = __shfl(row, src, 64);
     int n = __shfl(cnt, src, 64);                          // fill count of row r (register copy of the source lane)
     n = n < st.cap ? n : st.cap;
-    const float nt = st_compact(st, r, n, lane);
+    const float nt = st_select(st, r, n, lane);
     const int kept = n < st.k ? n : st.k;
     const bool mine = row == r;
     if (mine) {
