@@ -64,6 +64,13 @@ int sbr_host_mt19937_randint(unsigned int* key, int* pos, long high, long n, lon
  * the collate (data/dataloader.py:184-191) for its small redraw rounds, where a device round trip costs more than the search. */
 int sbr_host_csr_contains(const long* indptr, const int* indices, const long* users, const long* items, long n,
                           unsigned char* out);
+/* the whole default collate (NegativeSamplingDataLoader._neg_sampling_collate_fn, data/dataloader.py:154-198) of a small batch in one
+ * host call: draws every slot from the MT19937 stream (key, pos as for sbr_host_mt19937_randint), redraws the slots that hit one of
+ * their user's interactions (sorted CSR) round by round in ascending slot order, writes [B, 1 + n_neg] items (column 0 = positive).
+ * items_in_split NULL = identity; values, todo: scratch of B * n_neg longs. */
+int sbr_host_recbole_collate(unsigned int* key, int* pos, const long* users, const long* pos_items, long B, int n_neg, long n_cand,
+                             const long* items_in_split, const long* indptr, const int* indices, long* out_items, long* values,
+                             long* todo);
 
 /* Stable counting sort of the modality draw: the boolean-mask grouping of the flattened index tensor by sampled modality
  * (algorithms/sgd_alg.py:1934-1957). pos: int8 [R] modality position of every slot; segment m of slots_out

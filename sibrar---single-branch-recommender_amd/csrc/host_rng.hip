@@ -78,3 +78,83 @@ extern "C" int sbr_host_csr_contains(const long* indptr, const int* indices, con
   }
   return SBR_OK;
 }
+
+
+// ---- the whole default collate for small batches in one call -----------------------------------------------------------------
+// NegativeSamplingDataLoader._neg_sampling_collate_fn (data/dataloader.py:154-198) for batches whose B * n_neg slots are few
+// enough that the host search beats a GPU round trip (the reference's default batch, 256 x 10 slots): the Python version spends
+// most of its time in ~20 small numpy calls. Same draws in the same order: all slots (slot s belongs to user s % B), then
+// rounds that redraw only the colliding slots in ascending slot order, each value one masked-rejection draw of the MT19937
+// stream (np.random.choice(arr, m) == arr[np.random.randint(0, len(arr), m)], drawn sequentially).
+struct MtStream {
+  uint32_t* key;
+  int p;
+  uint32_t rng, mask;
+  inline long next() {
+    if (rng == 0) return 0;                                  // numpy draws nothing for a one-value range
+    for (;;) {
+      if (p == MT_N) { mt19937_regen(key); p = 0; }
+      uint32_t y = key[p++];
+      y ^= (y >> 11);
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= (y >> 18);
+      const uint32_t v = y & mask;
+      if (v <= rng) return (long)v;
+    }
+  }
+};
+
+static inline bool csr_has(const long* indptr, const int* indices, long u, long v) {
+  long lo = indptr[u], hi = indptr[u + 1];
+  const long end = hi;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (indices[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo < end && indices[lo] == v;
+}
+
+// users, pos_items: [B]; items_in_split: [n_cand] or NULL for the identity; (indptr, indices): sorted CSR of the split's
+// interactions; out_items: [B, 1 + n_neg] (column 0 = the positive); values, todo: scratch of B * n_neg longs each.
+extern "C" int sbr_host_recbole_collate(uint32_t* key, int* pos, const long* users, const long* pos_items, long B, int n_neg,
+                                        long n_cand, const long* items_in_split, const long* indptr, const int* indices,
+                                        long* out_items, long* values, long* todo) {
+  SBR_REQUIRE(key && pos && users && pos_items && indptr && indices && out_items && values && todo,
+              "sbr_host_recbole_collate: null operand");
+  SBR_REQUIRE(n_cand >= 1 && n_cand - 1 <= 0xFFFFFFFFL, "sbr_host_recbole_collate: n_cand=%ld outside [1, 2^32]", n_cand);
+  SBR_REQUIRE(*pos >= 0 && *pos <= MT_N, "sbr_host_recbole_collate: bad state position %d", *pos);
+  MtStream g;
+  g.key = key;
+  g.p = *pos;
+  g.rng = (uint32_t)(n_cand - 1);
+  g.mask = g.rng;
+  g.mask |= g.mask >> 1; g.mask |= g.mask >> 2; g.mask |= g.mask >> 4; g.mask |= g.mask >> 8; g.mask |= g.mask >> 16;
+  const long total = B * n_neg;
+  for (long s = 0; s < total; ++s) {
+    const long r = g.next();
+    values[s] = items_in_split ? items_in_split[r] : r;
+  }
+  long m = 0;
+  for (long s = 0; s < total; ++s)
+    if (csr_has(indptr, indices, users[s % B], values[s])) todo[m++] = s;
+  while (m > 0) {
+    for (long q = 0; q < m; ++q) {                           // one randint(n_cand, m) call: m sequential draws
+      const long r = g.next();
+      values[todo[q]] = items_in_split ? items_in_split[r] : r;
+    }
+    long m2 = 0;
+    for (long q = 0; q < m; ++q) {
+      const long s = todo[q];
+      if (csr_has(indptr, indices, users[s % B], values[s])) todo[m2++] = s;
+    }
+    m = m2;
+  }
+  for (long b = 0; b < B; ++b) {
+    long* o = out_items + b * (1 + n_neg);
+    o[0] = pos_items[b];
+    for (int j = 0; j < n_neg; ++j) o[1 + j] = values[(long)j * B + b];
+  }
+  *pos = g.p;
+  return SBR_OK;
+}

@@ -14,6 +14,7 @@ All functions return integer arrays; the parity bar is exact equality with the o
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -76,6 +77,10 @@ class PositiveIndex:
         self.n_items = int(csr.shape[1])
         rows = np.repeat(np.arange(csr.shape[0], dtype=np.int64), np.diff(csr.indptr))
         self.keys = np.sort(rows * self.n_items + csr.indices.astype(np.int64))
+        csr.sort_indices()
+        self._h_indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)       # for the native small-batch collate
+        self._h_indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
+    HOST_BELOW = 4096
 
     def contains(self, users: np.ndarray, items: np.ndarray) -> np.ndarray:
         q = users.astype(np.int64) * self.n_items + items.astype(np.int64)
@@ -147,6 +152,10 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     n_cand = len(items_in_split)
     if identity is None:
         identity = is_arange(items_in_split)
+    h_indptr = getattr(positives, '_h_indptr', None)
+    if (h_indptr is not None and 0 < total <= getattr(positives, 'HOST_BELOW', 0) * 2 and np.ndim(pos_item_idx) == 1
+            and 1 <= n_cand <= 0xFFFFFFFF and os.environ.get('SBR_NATIVE_COLLATE', '1') != '0'):
+        return _recbole_collate_native(user_idx, pos_item_idx, n_neg, items_in_split, identity, positives)
 
     def draw(m):
         # np.random.choice(arr, m, replace=True) == arr[np.random.randint(0, len(arr), m)] on the legacy global stream
@@ -166,6 +175,32 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     items[:, n_pos:] = values.reshape(n_neg, b).T
     labels = np.zeros(items.shape, dtype=float)
     labels[:, :n_pos] = 1.
+    return user_idx, items, labels
+
+
+def _recbole_collate_native(user_idx, pos_item_idx, n_neg, items_in_split, identity, positives):
+    """Small batches (the reference's default 256 x 10 slots): the whole collate in one native call (csrc/host_rng.hip,
+    sbr_host_recbole_collate) on the host copy of the interaction CSR — same draws from the global legacy stream, same
+    generator state afterwards as the numpy formulation above (tests/test_host_cpu.py)."""
+    import ctypes
+    from ._lib import lib
+    b = len(user_idx)
+    st = np.random.get_state()
+    key = np.array(st[1], dtype=np.uint32)
+    pos = ctypes.c_int(int(st[2]))
+    pos_items = np.ascontiguousarray(pos_item_idx, dtype=np.int64)
+    split = None if identity else np.ascontiguousarray(items_in_split, dtype=np.int64)
+    items = np.empty((b, 1 + n_neg), dtype=np.int64)
+    scratch = np.empty((2, b * n_neg), dtype=np.int64)
+    rc = lib().sbr_host_recbole_collate(key.ctypes.data, ctypes.byref(pos), user_idx.ctypes.data, pos_items.ctypes.data, b, n_neg,
+                                        len(items_in_split), None if split is None else split.ctypes.data,
+                                        positives._h_indptr.ctypes.data, positives._h_indices.ctypes.data, items.ctypes.data,
+                                        scratch[0].ctypes.data, scratch[1].ctypes.data)
+    if rc != 0:
+        raise RuntimeError(lib().sbr_last_error().decode())
+    np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+    labels = np.zeros(items.shape, dtype=float)
+    labels[:, 0] = 1.
     return user_idx, items, labels
 
 

@@ -338,3 +338,32 @@ def test_dataset_level_samplers_match_reference_streams(choice_set):
             ru, ri, rl = sampling_ref.dataset_sampler_collate(ds.interaction_matrix.row[sel], ds.interaction_matrix.col[sel], 3, strategy,
                                                               np.arange(I), positives, pop, 0.75)
             assert np.array_equal(u.numpy(), ru) and np.array_equal(i.numpy(), ri) and np.array_equal(l.numpy(), rl), strategy
+
+
+@pytest.mark.parametrize('B,n_neg,subset', [(16, 3, False), (256, 10, False), (64, 5, True), (1, 1, False), (300, 7, True)])
+def test_native_small_batch_collate_matches_the_numpy_formulation(B, n_neg, subset, monkeypatch):
+    """sbr_host_recbole_collate (one native call for the whole default collate of a small batch) == the numpy formulation of
+    recbole_negative_collate: same items, same labels, same generator state afterwards — on a dense world where most first
+    draws collide (many redraw rounds), with an identity and a gapped item set."""
+    from importlib import import_module
+    import scipy.sparse as sp
+    import sibrar_amd as S
+    sampling = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.sampling')
+    rng = np.random.default_rng(B * 31 + n_neg)
+    n_users, n_items = 40, 60
+    inter = sp.csr_matrix((rng.random((n_users, n_items)) < 0.6).astype(np.int8))       # 60 % of all pairs are positives
+    inter.sort_indices()
+    items_in_split = np.sort(rng.choice(n_items, size=45, replace=False)) if subset else np.arange(n_items)
+    users = rng.integers(0, n_users, size=B)
+    pos_items = rng.integers(0, n_items, size=B)
+    index = sampling.PositiveIndex(inter)
+    outs = []
+    for native in (False, True):
+        monkeypatch.setattr(sampling.PositiveIndex, 'HOST_BELOW', 1 << 20 if native else 0)
+        np.random.seed(123)
+        np.random.randint(0, 9, size=B % 17)                     # arbitrary position in the stream
+        u, i, l = sampling.recbole_negative_collate(users, pos_items, n_neg, items_in_split, index)
+        outs.append((u, i, l, np.random.randint(0, 1000, size=6)))
+    for a, b in zip(outs[0], outs[1]):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert not any(inter[u, v] for u, row in zip(outs[1][0], outs[1][1]) for v in row[1:])      # no negative is a positive
