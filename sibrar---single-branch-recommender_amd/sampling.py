@@ -153,7 +153,9 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     if identity is None:
         identity = is_arange(items_in_split)
     h_indptr = getattr(positives, '_h_indptr', None)
-    if (h_indptr is not None and 0 < total <= getattr(positives, 'HOST_BELOW', 0) * 2 and np.ndim(pos_item_idx) == 1
+    # a slot's user is user_idx[slot % B]: the B rows of the CSR that a batch touches become cache-resident after the first round,
+    # whatever the size of the CSR, so the host search is cheap for small batches even on large interaction matrices
+    if (h_indptr is not None and 0 < total <= int(os.environ.get('SBR_NATIVE_COLLATE_MAX', '8192')) and np.ndim(pos_item_idx) == 1
             and 1 <= n_cand <= 0xFFFFFFFF and os.environ.get('SBR_NATIVE_COLLATE', '1') != '0'):
         return _recbole_collate_native(user_idx, pos_item_idx, n_neg, items_in_split, identity, positives)
 

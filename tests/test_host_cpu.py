@@ -359,7 +359,7 @@ def test_native_small_batch_collate_matches_the_numpy_formulation(B, n_neg, subs
     index = sampling.PositiveIndex(inter)
     outs = []
     for native in (False, True):
-        monkeypatch.setattr(sampling.PositiveIndex, 'HOST_BELOW', 1 << 20 if native else 0)
+        monkeypatch.setenv('SBR_NATIVE_COLLATE', '1' if native else '0')
         np.random.seed(123)
         np.random.randint(0, 9, size=B % 17)                     # arbitrary position in the stream
         u, i, l = sampling.recbole_negative_collate(users, pos_items, n_neg, items_in_split, index)
