@@ -776,10 +776,7 @@ class FusedTrainStep:
     def close(self):
         """Drop the captured graphs (also done at interpreter exit: hipGraph objects must not outlive the HIP runtime) and bring
         a row-wise updated table up to date."""
-        try:
-            self.flush()
-        except Exception:
-            pass
+        self.flush()
         self._graphs.clear()
 
 
@@ -794,7 +791,10 @@ _LIVE = weakref.WeakSet()
 @atexit.register
 def _drop_graphs():
     for f in list(_LIVE):
-        f.close()
+        try:
+            f.close()
+        except Exception:          # interpreter teardown: the HIP runtime may already be gone
+            f._graphs.clear()
 
 
 class _CapturedStep:
