@@ -238,6 +238,10 @@ int sbr_mask_scores(float* scores, long ld, const long* u_idx, const long* excl_
                     void* stream);
 /* exact per-row top-k, sorted by (score desc, index asc) — torch.topk at eval/eval.py:320 and inside rmet.calculate */
 int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k, float* out_val, int* out_idx, void* stream);
+/* exact merge of W per-shard top-k lists of an item-sharded evaluation (new: the reference has no multi-GPU path):
+ * vals / idxs: [W, Bu, k] (all-gathered; idx < 0 = empty slot, idx = global item index), W * k <= 256 -> [Bu, k] sorted by
+ * (score desc, index asc). */
+int sbr_merge_topk(const float* vals, const int* idxs, int W, long Bu, int k, float* out_val, int* out_idx, void* stream);
 /* NDCG / recall / precision @ ks from top-k indices and CSR labels — eval/metrics.py:4-105. out: [3, n_ks, Bu]. */
 int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const long* label_indptr, const int* label_indices,
                      long Bu, const int* ks, int n_ks, float* out, void* stream);

@@ -271,6 +271,69 @@ extern "C" int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Exact merge of W per-shard top-k lists (item-sharded scoring, SURVEY 8(e): every rank scores its item shard, the lists are
+// all-gathered): out[b] = the k best of the W * k entries (score desc, item index asc — the rule every top-k kernel here
+// uses; idx < 0 marks an empty slot). One wave per user; every entry is ranked against all others by counting over
+// v_readlane broadcasts (W * k <= 256: up to four entries per lane), the entry of rank j writes output position j.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ vals, const int* __restrict__ idxs, int W,
+                                                         long Bu, int k, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  const long b = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= Bu) return;
+  const int lane = threadIdx.x & 63;
+  const int n = W * k;                                        // <= 256
+  unsigned long long e[4];
+  int rank[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = lane + 64 * q;
+    e[q] = 0ull;
+    rank[q] = 0;
+    if (j < n) {
+      const int w = j / k, r = j - w * k;
+      const long src = ((long)w * Bu + b) * k + r;
+      const int id = idxs[src];
+      if (id >= 0) e[q] = ((unsigned long long)f2key(vals[src]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int hi = (int)(e[q] >> 32), lo = (int)e[q];
+    const int m = n - 64 * q < 64 ? n - 64 * q : 64;
+    for (int j = 0; j < m; ++j) {
+      const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(hi, j) << 32) |
+                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(lo, j);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rank[p] += kj > e[p];
+    }
+  }
+  // empty entries (composite 0) rank behind every real one but tie with each other: they fill the remaining positions below
+  int n_real = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) n_real += __popcll(__ballot(e[q] != 0ull));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (e[q] != 0ull && rank[q] < k) {
+      out_val[b * k + rank[q]] = key2f((unsigned int)(e[q] >> 32));
+      out_idx[b * k + rank[q]] = (int)(0xFFFFFFFFu - (unsigned int)(e[q] & 0xFFFFFFFFull));
+    }
+  }
+  for (int j = n_real + lane; j < k; j += 64) {
+    out_val[b * k + j] = -INFINITY;
+    out_idx[b * k + j] = -1;
+  }
+}
+
+extern "C" int sbr_merge_topk(const float* vals, const int* idxs, int W, long Bu, int k, float* out_val, int* out_idx, void* stream) {
+  SBR_REQUIRE(W >= 1 && k >= 1 && (long)W * k <= 256, "sbr_merge_topk: W * k = %ld outside [1, 256]", (long)W * k);
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(vals && idxs && out_val && out_idx, "sbr_merge_topk: null operand");
+  merge_topk_kernel<<<sbr_cdiv(Bu, 4), 256, 0, (hipStream_t)stream>>>(vals, idxs, W, Bu, k, out_val, out_idx);
+  SBR_CHECK_LAUNCH("sbr_merge_topk");
+  return SBR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // ranking metrics with binary relevance (eval/metrics.py): for each user b and each cutoff ks[q]
 //   hits   = #{r < k : topk[b, r] in labels(u_b)}
 //   recall = hits / n_pos (0 when n_pos == 0), precision = hits / k,

@@ -83,10 +83,22 @@ def merge_topk(val: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tens
 
 
 def all_gather_topk(val: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather every rank's [Bu, k] shard lists and merge them; every rank ends with the global top-k."""
+    """All-gather every rank's [Bu, k] shard lists and merge them; every rank ends with the global top-k. On the GPU the lists
+    are gathered into one [W, Bu, k] buffer each and merged by ``sbr_merge_topk`` (one wave per user); the torch formulation
+    (``merge_topk``) serves CPU tensors (gloo tests) and W * k > 256."""
     if not is_distributed():
         return val, idx
     world = dist.get_world_size()
+    if val.is_cuda and world * k <= 256 and idx.dtype == torch.int32:
+        from ._lib import call, ptr, stream
+        Bu = val.shape[0]
+        vals = torch.empty(world, Bu, k, device=val.device, dtype=torch.float32)
+        idxs = torch.empty(world, Bu, k, device=val.device, dtype=torch.int32)
+        dist.all_gather_into_tensor(vals.view(-1), val.contiguous().float().view(-1))
+        dist.all_gather_into_tensor(idxs.view(-1), idx.contiguous().view(-1))
+        out_val, out_idx = torch.empty_like(val, dtype=torch.float32), torch.empty_like(idx)
+        call('sbr_merge_topk', ptr(vals), ptr(idxs), world, Bu, k, ptr(out_val), ptr(out_idx), stream())
+        return out_val, out_idx
     vals = [torch.empty_like(val) for _ in range(world)]
     idxs = [torch.empty_like(idx) for _ in range(world)]
     dist.all_gather(vals, val.contiguous())

@@ -575,3 +575,27 @@ def test_deferred_row_wise_adam_replay_is_bit_identical(name):
     d.flush()
     assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
     assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
+
+
+@pytest.mark.parametrize('W,Bu,k', [(1, 5, 3), (2, 300, 20), (8, 1000, 20), (8, 77, 32), (4, 50, 1)])
+def test_merge_topk_kernel_equals_the_host_merge(W, Bu, k):
+    """sbr_merge_topk (item-sharded evaluation: the all-gathered per-shard lists) == parallel.merge_topk (torch formulation, pinned
+    on the CPU by tests/test_host_cpu.py): ties across shards resolved by item index, empty slots (idx -1) last."""
+    from importlib import import_module
+    Sm = S()
+    _lib = import_module(Sm.ops.__name__.rsplit('.', 1)[0] + '._lib')
+    g = torch.Generator().manual_seed(W * 100 + k)
+    vals = (torch.randint(0, 40, (W, Bu, k), generator=g).float() / 8).sort(dim=2, descending=True).values   # many ties
+    idxs = torch.stack([torch.stack([torch.randperm(1000, generator=g)[:k] + 1000 * w for _ in range(Bu)]) for w in range(W)]).int()
+    n_valid = torch.randint(0, k + 1, (W, Bu), generator=g)                              # shards with fewer than k entries
+    empty = torch.arange(k)[None, None, :] >= n_valid[..., None]
+    idxs[empty] = -1
+    vals[empty] = -float('inf')
+    out_val = torch.empty(Bu, k, device=DEV)
+    out_idx = torch.empty(Bu, k, dtype=torch.int32, device=DEV)
+    vals_d, idxs_d = vals.to(DEV), idxs.to(DEV)
+    _lib.call('sbr_merge_topk', vals_d.data_ptr(), idxs_d.data_ptr(), W, Bu, k, out_val.data_ptr(), out_idx.data_ptr(), _lib.stream())
+    rv, ri = Sm.parallel.merge_topk(torch.cat(list(vals), dim=1), torch.cat(list(idxs), dim=1), k)
+    assert torch.equal(out_idx.cpu(), ri.int())
+    got, want = out_val.cpu(), rv
+    assert torch.equal(torch.isinf(got), torch.isinf(want)) and torch.equal(got[~torch.isinf(got)], want[~torch.isinf(want)])
