@@ -114,7 +114,13 @@ class FullEvaluator:
             n_items = self.dataset.n_items_in_split if self.dataset is not None else int(top.max()) + 1
             for k in self._ks:
                 if k <= top.shape[1]:
-                    metrics[self._key('coverage', k)] = torch.unique(top[:, :k]).numel() / n_items
+                    # distinct recommended items: mark-and-count over the item range (torch.unique sorts its 2M inputs: ~0.7 ms
+                    # per cut-off on c2); empty slots (-1: users with fewer than k scoreable items) are not items
+                    ids = top[:, :k].reshape(-1).long()
+                    ids = ids[ids >= 0]
+                    seen = torch.zeros(max(int(n_items), int(ids.max()) + 1 if ids.numel() else 1), dtype=torch.bool, device=top.device)
+                    seen[ids] = True
+                    metrics[self._key('coverage', k)] = int(seen.sum()) / n_items
         metrics = {k: metrics[k] for k in sorted(metrics)}
         self._reset()
         return (metrics, raw) if return_raw_results else metrics
