@@ -61,8 +61,15 @@ class FullEvaluator:
     def _labels(self, device):
         if self._labels_dev is None or self._labels_dev[0].device != torch.device(device):
             ds = self.dataset
-            lab = sp.csr_matrix(ds.user_sampling_matrix)[:, np.asarray(ds.items_in_split)]
-            self._labels_dev = _csr_to_device(lab, device)
+            cached = getattr(ds, '_labels_dev', None)          # evaluators come and go (one per evaluation), the split does not
+            if cached is None or cached[0].device != torch.device(device):
+                lab = sp.csr_matrix(ds.user_sampling_matrix)[:, np.asarray(ds.items_in_split)]
+                cached = _csr_to_device(lab, device)
+                try:
+                    ds._labels_dev = cached
+                except Exception:
+                    pass
+            self._labels_dev = cached
         return self._labels_dev
 
     def eval_topk(self, u_idxs: torch.Tensor, topk_idx: torch.Tensor):
