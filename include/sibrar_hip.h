@@ -48,6 +48,15 @@ int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx, const flo
                  const float* bias, float* C, long ldc, const int* c_idx, int M, int N, int K, int act,
                  int accumulate_atomic, void* stream);
 
+/* NT (mode 0 of sbr_gemm_f32: nn.Linear forward with fused bias / activation / row gather / row scatter) for products with few
+ * output tiles and a long K — the modality projectors at the reference's default batch of 256: K is split over workgroups, the
+ * partial tiles are summed in a fixed order by a second kernel that applies bias, activation and the scatter.
+ * sbr_gemm_nt_splitk_workspace() returns 0 for shapes that should go to sbr_gemm_f32 instead. */
+long sbr_gemm_nt_splitk_workspace(int M, int N, int K);
+int sbr_gemm_nt_splitk_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const float* bias, float* C,
+                           long ldc, const int* c_idx, int M, int N, int K, int act, void* workspace, long workspace_bytes,
+                           void* stream);
+
 /* TN with a deterministic split-K slab reducer (no atomics): C[m, n] = sum_k A[ak(k), m] * B[bk(k), n], C overwritten.
  * autograd of nn.Linear w.r.t. its weight (dW = dZ^T X[rows]). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes. */
 long sbr_gemm_tn_f32_workspace(int M, int N, int K);

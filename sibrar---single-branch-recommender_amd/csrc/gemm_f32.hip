@@ -367,6 +367,69 @@ extern "C" int sbr_gemm_f32(int mode, const float* A, long lda, const int* a_idx
   return launch<2, 2, 2, 2, false, false>(g, 1, s);
 }
 
+// ---- NT with a split-K slab reducer: few output tiles, long K ------------------------------------------------------------------
+// The modality projectors at the reference's default batch (1,408 gathered rows x 768 features -> 128: 22 output tiles) leave
+// 90 % of the CUs idle while each workgroup walks 24 K slabs one after the other (36 us). K is split so that ~128+ work items
+// exist; the partial tiles go to slabs and a second kernel sums them in a fixed order (bitwise reproducible) and applies bias,
+// activation and the output row scatter.
+__global__ void splitk_reduce_epilogue_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                              const float* __restrict__ bias, int act, float* __restrict__ C, long ldc,
+                                              const int* __restrict__ c_idx) {
+  const long total = (long)M * N;
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += slab[z * total + e];
+  const int m = (int)(e / N), n = (int)(e - (long)m * N);
+  if (bias) v += bias[n];
+  C[(c_idx ? (long)c_idx[m] : (long)m) * ldc + n] = sbr_act(v, act);
+}
+
+static int nt_splits(int M, int N, int K) {
+  const long tiles = (long)sbr_cdiv(M, 64) * sbr_cdiv(N, 128);
+  if (tiles >= 96 || K < 8 * BK) return 1;                 // enough tiles to fill the chip, or too little K to share
+  int splits = (int)((192 + tiles - 1) / tiles);            // aim at ~192 work items
+  const int max_splits = K / (4 * BK);                      // at least 4 slabs per item
+  if (splits > max_splits) splits = max_splits;
+  if (getenv("SBR_NT_SPLITS")) splits = atoi(getenv("SBR_NT_SPLITS"));      // tuning aid (0 / 1 = off)
+  return splits < 2 ? 1 : splits;
+}
+
+extern "C" long sbr_gemm_nt_splitk_workspace(int M, int N, int K) {
+  const int splits = nt_splits(M, N, K);
+  return splits > 1 ? (long)splits * M * N * (long)sizeof(float) : 0;
+}
+
+// C[ci(m), n] = act(sum_k A[ai(m), k] * B[n, k] + bias[n]) for the shapes sbr_gemm_nt_splitk_workspace() returns > 0 for
+// (otherwise use sbr_gemm_f32 mode 0). workspace: that many bytes.
+extern "C" int sbr_gemm_nt_splitk_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const float* bias,
+                                      float* C, long ldc, const int* c_idx, int M, int N, int K, int act, void* workspace,
+                                      long workspace_bytes, void* stream) {
+  SBR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sbr_gemm_nt_splitk_f32: negative size");
+  if (M == 0 || N == 0) return SBR_OK;
+  SBR_REQUIRE(A && B && C, "sbr_gemm_nt_splitk_f32: null operand");
+  int splits = nt_splits(M, N, K);
+  SBR_REQUIRE(splits > 1, "sbr_gemm_nt_splitk_f32: shape %d x %d x %d is not split (use sbr_gemm_f32)", M, N, K);
+  SBR_REQUIRE(workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float), "sbr_gemm_nt_splitk_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = nullptr; g.bias = nullptr;
+  g.C = C; g.ldc = ldc; g.c_idx = nullptr; g.M = M; g.N = N; g.K = K; g.act = SBR_ACT_NONE;
+  g.vecA = aligned16(A, lda); g.vecB = aligned16(B, ldb);
+  g.atomic = 0;
+  g.slab = (float*)workspace;
+  g.k_chunk = sbr_cdiv(sbr_cdiv(K, splits), BK) * BK;
+  splits = sbr_cdiv(K, g.k_chunk);
+  g.splits = splits;
+  int rc = sbr_gemm_ring_launch(0, g, s);
+  if (rc < 0) rc = launch<2, 2, 1, 2, false, false>(g, splits, s);
+  if (rc) return rc;
+  const long total = (long)M * N;
+  splitk_reduce_epilogue_kernel<<<sbr_cdiv(total, 256), 256, 0, s>>>(g.slab, splits, M, N, bias, act, C, ldc, c_idx);
+  SBR_CHECK_LAUNCH("sbr_gemm_nt_splitk_f32/reduce");
+  return SBR_OK;
+}
+
 // ---- TN with a split-K slab reducer ------------------------------------------------------------------------------------
 static int tn_splits(int M, int N, int K) {
   const int tiles = sbr_cdiv(M, 64) * sbr_cdiv(N, 128);

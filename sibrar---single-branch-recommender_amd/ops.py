@@ -82,6 +82,14 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
     N, K = W.shape
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    ws_bytes = lib().sbr_gemm_nt_splitk_workspace(M, N, K) if M > 0 else 0
+    if ws_bytes > 0:
+        # few output tiles, long K (the modality projectors at small batches): K split over workgroups, deterministic reduce
+        ws = _tn_workspace(x.device, ws_bytes)
+        _timed(('gemm_f32', 0, M, N, K, a_idx is not None),
+               lambda: call('sbr_gemm_nt_splitk_f32', ptr(x), x.stride(0), ptr(a_idx), ptr(W), W.stride(0), ptr(bias), ptr(out),
+                            out.stride(0), ptr(c_idx), M, N, K, act, ptr(ws), ws.numel() * 4, stream()))
+        return out
     gemm(0, x, x.stride(0), a_idx, W, W.stride(0), None, bias, out, out.stride(0), c_idx, M, N, K, act, 0)
     return out
 

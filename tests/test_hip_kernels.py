@@ -49,6 +49,32 @@ def test_gemm_nt_gather_scatter_unaligned():
     close(out.cpu(), ref, rtol=1e-4, atol=1e-5, what='gather/scatter')
 
 
+@pytest.mark.parametrize('M,N,K,act', [(1408, 128, 768, 1), (64, 128, 1024, 0), (300, 200, 512, 2), (7, 64, 2048, 1)])
+def test_gemm_nt_split_k_with_gather_scatter(M, N, K, act):
+    """Few output tiles and a long K (the modality projectors at the reference's default batch): sbr_gemm_nt_splitk_f32 — K
+    split over workgroups, fixed-order reduction with bias, activation and output row scatter — against fp64; two runs are
+    bit-identical."""
+    ops = S().ops
+    from importlib import import_module
+    _lib = import_module(ops.__name__.rsplit('.', 1)[0] + '._lib')
+    assert _lib.lib().sbr_gemm_nt_splitk_workspace(M, N, K) > 0
+    table = _rand(M + 50, K, seed=31)
+    w, b = _rand(N, K, seed=32) / math.sqrt(K), _rand(N, seed=33)
+    g = torch.Generator().manual_seed(34)
+    rows = torch.randint(0, M + 50, (M,), generator=g, dtype=torch.int32)
+    slots = torch.randperm(M + 9, generator=g)[:M].to(torch.int32)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M + 9, N), 3.0, device=DEV)
+        ops.linear_nt(table.to(DEV), w.to(DEV), b.to(DEV), act, a_idx=rows.to(DEV), out=out, c_idx=slots.to(DEV), n_rows=M)
+        outs.append(out.cpu())
+    pre = table[rows.long()].double() @ w.double().t() + b.double()
+    ref = torch.full((M + 9, N), 3.0, dtype=torch.float64)
+    ref[slots.long()] = {0: pre, 1: torch.relu(pre), 2: torch.tanh(pre)}[act]
+    close(outs[0], ref, rtol=1e-4, atol=1e-5, what='split-K NT', norm_rtol=2e-6, scale=float(pre.abs().max()))
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('M,N,K', [(3, 5, 7), (70, 33, 129), (513, 64, 64), (100, 768, 64)])
 def test_gemm_nn_and_tn(M, N, K):
     ops = S().ops
