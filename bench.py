@@ -99,6 +99,11 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     # 2 * prefetch + 2 batches ahead while the first steps compile / capture, and a timed region that starts on that head start
     # would report the consumer's burst rate instead of the sustained rate of the whole pipeline.
     run_steps(S, trainer, it, warmup + SETTLE, world)
+    # no cyclic-garbage collection inside the timed region (a generation-2 pass over the loader's queues and tensors is a
+    # multi-millisecond pause on the launch thread); collected before, re-enabled after
+    import gc
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -108,6 +113,7 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     LAST_LOSS[batch] = float(last[0]) if last is not None else None      # sanity of the timed steps (read after the clock)
     if LAST_LOSS[batch] is not None and not (0.0 < LAST_LOSS[batch] < 1e3):
         raise RuntimeError(f'training loss after the timed region is {LAST_LOSS[batch]}: the timed steps did not train')
@@ -319,7 +325,7 @@ def cpu_baseline(S, ds, net, batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch-size', type=int, default=8192, help='per-GPU batch (positive interactions per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

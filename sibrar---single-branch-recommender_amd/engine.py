@@ -115,9 +115,12 @@ class _EntityRun:
                                       f'{ops.PARTITION_MAX_MODALITIES})')
         counts = np.bincount(flat, minlength=len(order))
         if pad:
-            bucket = 64
-            while bucket * bucket < 4 * R:
-                bucket *= 2
+            # half a bucket on either side of the expected count must cover the draw's spread for practically every step: a
+            # count outside means a new signature — a step of plain launches and, at its second sighting, a capture (~12 ms:
+            # with 3.4 sigma per side one bench run in eight measured 0.98 instead of 0.86 ms per step). sigma <= sqrt(R) / 2, so
+            # a bucket of 5 sqrt(R) (rounded up to 64) is >= 5 sigma per side (c2 at B = 8192: 1536, i.e. 768 padded rows
+            # on average instead of 512).
+            bucket = max(64, -(-int(5.0 * math.sqrt(R)) // 64) * 64)
             # bucket grid shifted so that the expected count R / n_modalities sits in the MIDDLE of a bucket (+- 2 sigma and
             # more on either side): one signature then covers nearly every step. With the grid at multiples of the bucket a
             # count whose mean is such a multiple (c2: 45056 = 44 * 1024) flips between two capacities from step to step.
