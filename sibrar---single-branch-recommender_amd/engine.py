@@ -113,7 +113,9 @@ class _EntityRun:
         if len(order) > ops.PARTITION_MAX_MODALITIES:
             raise NotImplementedError(f'{len(order)} modalities on one entity (the slot partition kernel handles '
                                       f'{ops.PARTITION_MAX_MODALITIES})')
-        counts = np.bincount(flat, minlength=len(order))
+        # per-modality counts: one vectorised compare-and-count per modality (np.bincount converts the int8 array to intp first:
+        # 0.1 ms at 90k slots, a quarter of the whole prepare stage)
+        counts = np.array([np.count_nonzero(flat == m) for m in range(len(order))], dtype=np.int64)
         if pad:
             # half a bucket on either side of the expected count must cover the draw's spread for practically every step: a
             # count outside means a new signature — a step of plain launches and, at its second sighting, a capture (~12 ms:
