@@ -73,6 +73,8 @@ int sbr_host_mt19937_randint(unsigned int* key, int* pos, long high, long n, lon
  * the collate (data/dataloader.py:184-191) for its small redraw rounds, where a device round trip costs more than the search. */
 int sbr_host_csr_contains(const long* indptr, const int* indices, const long* users, const long* items, long n,
                           unsigned char* out);
+/* HOST: the layout step of the collate (data/dataloader.py:192-195): items[b, 0] = pos_items[b], items[b, 1 + j] = values[j * B + b]. */
+int sbr_host_assemble_items(const long* pos_items, const long* values, long B, int n_neg, long* out_items);
 /* the whole default collate (NegativeSamplingDataLoader._neg_sampling_collate_fn, data/dataloader.py:154-198) of a small batch in one
  * host call: draws every slot from the MT19937 stream (key, pos as for sbr_host_mt19937_randint), redraws the slots that hit one of
  * their user's interactions (sorted CSR) round by round in ascending slot order, writes [B, 1 + n_neg] items (column 0 = positive).

@@ -173,11 +173,32 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
         todo = todo[positives.contains(slot_user[todo], values[todo])]
     items = np.empty((b, 1 + n_neg) if np.ndim(pos_item_idx) == 1 else (b, pos_item_idx.shape[-1] + n_neg), dtype=np.int64)
     n_pos = items.shape[1] - n_neg
-    items[:, :n_pos] = np.asarray(pos_item_idx).reshape(b, n_pos)
-    items[:, n_pos:] = values.reshape(n_neg, b).T
-    labels = np.zeros(items.shape, dtype=float)
-    labels[:, :n_pos] = 1.
-    return user_idx, items, labels
+    if n_pos == 1 and values.flags.c_contiguous:
+        from ._lib import lib
+        pos_c = np.ascontiguousarray(pos_item_idx, dtype=np.int64)
+        if lib().sbr_host_assemble_items(pos_c.ctypes.data, values.ctypes.data, b, n_neg, items.ctypes.data) != 0:
+            raise RuntimeError(lib().sbr_last_error().decode())
+    else:
+        items[:, :n_pos] = np.asarray(pos_item_idx).reshape(b, n_pos)
+        items[:, n_pos:] = values.reshape(n_neg, b).T
+    return user_idx, items, _first_columns_positive(items.shape, n_pos)
+
+
+_LABELS = {}
+
+
+def _first_columns_positive(shape, n_pos):
+    """The label matrix of the collates (first n_pos columns 1, negatives 0, float64 — data/dataloader.py:196-197): the same for
+    every batch of a shape, so one read-only array per shape is handed out instead of a fresh 0.7 MB one per batch."""
+    key = (tuple(shape), n_pos)
+    lab = _LABELS.get(key)
+    if lab is None:
+        lab = np.zeros(shape, dtype=float)
+        lab[:, :n_pos] = 1.
+        lab.setflags(write=False)
+        if len(_LABELS) < 64:
+            _LABELS[key] = lab
+    return lab
 
 
 def _recbole_collate_native(user_idx, pos_item_idx, n_neg, items_in_split, identity, positives):
