@@ -184,10 +184,29 @@ __global__ void gather_rows_kernel(const float* __restrict__ W, long ldw, const 
   }
 }
 
+// 16 bytes per thread, one thread per (row, 4-column chunk), no grid-stride loop: the scalar kernel above keeps one dependent
+// 4-byte load in flight per thread and runs at memory latency (45k rows x 128: 14 us = 2 TB/s of useful traffic)
+__global__ void gather_rows4_kernel(const float* __restrict__ W, long ldw, const int* __restrict__ rows,
+                                    float* __restrict__ out, long ldo, const int* __restrict__ out_idx, long n, int D4) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= n * D4) return;
+  const long j = e / D4;
+  const int c = (int)(e - j * D4) * 4;
+  const long o = out_idx ? out_idx[j] : j;
+  *reinterpret_cast<float4*>(out + o * ldo + c) = *reinterpret_cast<const float4*>(W + (long)rows[j] * ldw + c);
+}
+
 extern "C" int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx,
                                long n, int D, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(W && rows && out, "sbr_gather_rows: null operand");
+  if ((D & 3) == 0 && (ldw & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)W) | ((uintptr_t)out)) & 15) == 0 &&
+      n * (D / 4) < (1L << 31) * 256) {
+    const long total4 = n * (D / 4);
+    gather_rows4_kernel<<<(unsigned)sbr_cdiv(total4, 256), 256, 0, (hipStream_t)stream>>>(W, ldw, rows, out, ldo, out_idx, n, D / 4);
+    SBR_CHECK_LAUNCH("sbr_gather_rows");
+    return SBR_OK;
+  }
   int blocks = sbr_cdiv(n * D, 256);
   if (blocks > 4096) blocks = 4096;
   gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(W, ldw, rows, out, ldo, out_idx, n, D);
@@ -212,6 +231,8 @@ extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_i
                                     long ldw, long n, int D, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(dOut && rows && dW, "sbr_scatter_add_rows: null operand");
+  // (Tried: 16-byte loads + four atomics per thread. Each atomic instruction of a wave then touches every fourth float —
+  // four times the L2 atomic transactions of the lane-contiguous scalar kernel: the step went from 0.86 to 0.98 ms.)
   int blocks = sbr_cdiv(n * D, 256);
   if (blocks > 4096) blocks = 4096;
   scatter_add_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n, D);
