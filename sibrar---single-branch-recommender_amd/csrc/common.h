@@ -106,18 +106,6 @@ __device__ __forceinline__ void sbr_col_reduce(long n, int D, double* __restrict
   for (int k = 0; k < K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < RL) {
     long j = lo + rl;
-    // eight rows per pass first: 512 blocks x 256 threads x 16 bytes is 2 MB per row in flight, and at ~2 us of HBM latency four
-    // rows in flight cap the kernel at ~4 TB/s (measured: column sums 4.0, BatchNorm statistics 3.5 TB/s)
-    for (; j + 7L * RL < hi; j += 8L * RL) {
-      float4 v0[K], v1[K], v2[K], v3[K], v4[K], v5[K], v6[K], v7[K];
-      f(j, cg, v0); f(j + RL, cg, v1); f(j + 2L * RL, cg, v2); f(j + 3L * RL, cg, v3);
-      f(j + 4L * RL, cg, v4); f(j + 5L * RL, cg, v5); f(j + 6L * RL, cg, v6); f(j + 7L * RL, cg, v7);
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        sbr_f4_add(v0[k], v1[k]); sbr_f4_add(v2[k], v3[k]); sbr_f4_add(v4[k], v5[k]); sbr_f4_add(v6[k], v7[k]);
-        sbr_f4_add(v0[k], v2[k]); sbr_f4_add(v4[k], v6[k]); sbr_f4_add(v0[k], v4[k]); sbr_f4_add(acc[k], v0[k]);
-      }
-    }
     for (; j + 3L * RL < hi; j += 4L * RL) {
       float4 v0[K], v1[K], v2[K], v3[K];
       f(j, cg, v0); f(j + RL, cg, v1); f(j + 2L * RL, cg, v2); f(j + 3L * RL, cg, v3);
