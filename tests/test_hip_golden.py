@@ -581,6 +581,36 @@ def test_fused_step_with_deferred_row_wise_adam_equals_dense_optimizer(optimizer
 
 
 @pytest.mark.gpu
+def test_two_rank_data_parallel_rehearsal_on_one_gpu():
+    """The whole multi-process path of bench.py with TWO ranks sharing this box's one GPU (gloo carries the collectives; RCCL
+    refuses two ranks on one device): rank-local sampling, two-phase step, all-gather exchange of the lookup user rows with the
+    deterministic sorted scatter, dense all-reduce of the rest, item-sharded scoring with the top-k all-gather + merge kernel.
+    The replicas' parameters must agree exactly after the run and training must have made progress."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, SBR_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '20', '--warmup', '3',
+           '--no-b256']
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2'
+    assert out['config']['replica_param_checksum_spread'] == 0.0
+    assert 'all-gather' in out['config']['user_table_gradient_exchange']
+    assert 0.0 < out['config']['loss_after_timed_steps'] < 2.45          # ln(11) = 2.40 at initialisation, falling
+    assert out['scoring']['sharding'] == 'items/2' and out['scoring']['value'] > 0
+
+
+@pytest.mark.gpu
 def test_loader_pipeline_equals_inline_steps():
     """Batches prepared ahead by the loader's two producer threads (collate -> FusedTrainStep.prepare with pinned packed
     uploads, device-cached labels, graph replay) train the model exactly like the same batches stepped inline."""
