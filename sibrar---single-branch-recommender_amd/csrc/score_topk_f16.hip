@@ -14,9 +14,10 @@
 // tile whose ballots stay in SGPRs, OR-reduced to one branch). The rare survivors are tested against the tile's exclusion
 // bits (each lower-half lane walks the sorted exclusion CSR row of one user in step with the tiles; look-ahead entries arrive
 // by 4-byte LDS-DMA so that the loop contains no ordinary global load) and appended to the row's candidate buffer in LDS at
-// positions derived from the wave ballot (no atomics). A full buffer is compacted by its owning wave (rank by counting over
-// v_readlane broadcasts), which raises the row's threshold. Rows are owned by exactly one wave: the top-k state needs no
-// cross-wave synchronisation.
+// positions derived from the wave ballot (no atomics). A full buffer is compacted by its owning wave — during the stream by
+// SELECTION of the k best (st_select: bitwise binary search of the k-th key over ballot counts), in the final pass by ranking
+// (st_compact: counting over LDS broadcasts, sorted output) — which raises the row's threshold. Rows are owned by exactly one
+// wave: the top-k state needs no cross-wave synchronisation. This kernel serves D = 256; D <= 128 takes the wide kernel below.
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
