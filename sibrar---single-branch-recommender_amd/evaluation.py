@@ -112,7 +112,12 @@ class FullEvaluator:
             self.eval_topk(u_idxs, idx)
 
     def get_results(self, return_raw_results: bool = False):
-        raw = {k: torch.cat(v).cpu().numpy() for k, v in self._results.items()}
+        keys = list(self._results)
+        if keys:                       # one device -> host transfer for all metrics instead of one (and one sync) per metric
+            stacked = torch.stack([torch.cat(self._results[k]).float() for k in keys]).cpu().numpy()
+            raw = {k: stacked[i] for i, k in enumerate(keys)}
+        else:
+            raw = {}
         metrics = {k: float(v.mean()) for k, v in raw.items()}
         if getattr(self.config, 'calculate_std', False):
             metrics.update({f'{k}_std': float(v.std()) for k, v in raw.items()})
