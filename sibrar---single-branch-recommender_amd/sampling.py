@@ -189,13 +189,13 @@ _LABELS = {}
 
 def _first_columns_positive(shape, n_pos):
     """The label matrix of the collates (first n_pos columns 1, negatives 0, float64 — data/dataloader.py:196-197): the same for
-    every batch of a shape, so one read-only array per shape is handed out instead of a fresh 0.7 MB one per batch."""
+    every batch of a shape, so one array per shape is handed out instead of a fresh 0.7 MB one per batch (consumers treat labels as read-only; a writable
+    array keeps torch.from_numpy quiet)."""
     key = (tuple(shape), n_pos)
     lab = _LABELS.get(key)
     if lab is None:
         lab = np.zeros(shape, dtype=float)
         lab[:, :n_pos] = 1.
-        lab.setflags(write=False)
         if len(_LABELS) < 64:
             _LABELS[key] = lab
     return lab
