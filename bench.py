@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — training interactions/s (+ full-catalogue scores/s) of the HIP SingleBranchNet engine on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL. Either an external launcher provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``), or — WORLD_SIZE unset — this script starts
+the N rank processes itself before touching the GPU (``launch_ranks``). A process group whose size differs from ``--gpus``
+or whose backend is not RCCL is a hard error.
 
 Workload (BASELINE.json configs[1], "c2"): synthetic 100k users x 50k items, ~5M interactions, one 768-d dense item
 modality + item-id embedding, common/shared dim 128, hidden [128], sampled-softmax loss, 10 negatives, AdamW(1e-3, 1e-6);
@@ -322,6 +327,38 @@ def cpu_baseline(S, ds, net, batch, budget_s=20.0):
                       f'torch {torch.__version__} CPU fp32, {cores} threads)', 'step_seconds': step_s}
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without an external launcher: start N rank processes of this script (one per GPU, the
+    environment torch.distributed.run would give them, rendezvous on 127.0.0.1) BEFORE this process has made any GPU / HIP
+    call, wait for them and return the worst exit code. Rank 0 prints the JSON line on the inherited stdout. When a rank
+    fails the others — which would wait for it in a collective forever — are terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SBR_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on these hosts (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -334,6 +371,10 @@ def main():
     ap.add_argument('--small', action='store_true', help='1/10-size workload (debug only; never a reportable number)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: become the launcher (nothing in this process has touched the GPU yet)
+        sys.exit(launch_ranks(args.gpus))
+
     import torch.distributed as dist
     if 'SBR_SWITCH_INTERVAL' in os.environ:
         sys.setswitchinterval(float(os.environ['SBR_SWITCH_INTERVAL']))
@@ -345,7 +386,15 @@ def main():
     # SBR_DIST_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-process path on a one-GPU box (ranks share cuda:0,
     # collectives staged through the host) — never a reportable number
     backend = os.environ.get('SBR_DIST_BACKEND', 'nccl')
-    local = local % max(torch.cuda.device_count(), 1)
+    rehearsal = backend != 'nccl'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU '
+                         f'(python bench.py --gpus N starts them itself)')
+    n_dev = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+    if world > 1 and not rehearsal and n_dev < world:
+        raise SystemExit(f'bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {n_dev} '
+                         f'(SBR_DIST_BACKEND=gloo rehearses the multi-process path on fewer GPUs; never a reportable number)')
+    local = local % max(n_dev, 1)
     # SBR_FORCE_DIST=1: one-rank process group with the gradient / top-k exchange switched on (rehearsal of the RCCL call
     # sequence on a one-GPU box — never a reportable number)
     force_dist = world == 1 and os.environ.get('SBR_FORCE_DIST', '0') == '1'
@@ -358,9 +407,19 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = f'cuda:{local}'
     torch.cuda.set_device(local)
+    ranks_seen, backend_used = 1, None
+    if dist.is_initialized():
+        # the communicator that actually formed: every rank adds one
+        seen = torch.ones(1, device=device, dtype=torch.int64)
+        dist.all_reduce(seen)
+        ranks_seen, backend_used = int(seen.item()), dist.get_backend()
+        if dist.get_world_size() != args.gpus or (ranks_seen != args.gpus and not force_dist):
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks '
+                             f'({ranks_seen} answered)')
+        if backend_used != 'nccl' and not rehearsal:
+            raise SystemExit(f'bench.py: backend {backend_used!r} is not RCCL')
 
     import sibrar_amd as S
     cfg = dict(C2)
@@ -378,7 +437,10 @@ def main():
                                'sampled-softmax, 10 negatives, AdamW; user = embedding lookup, item = SingleBranchNet entity '
                                '(text 768-d + item-id embedding, hidden [128], BatchNorm)' + (' [SMALL DEBUG SIZE]' if args.small else ''),
                    'batch_per_gpu': args.batch_size, 'global_batch': args.batch_size * world, 'n_negatives': cfg['n_neg'],
-                   'parallelism': f'dp{world}' if world > 1 else 'single', 'settle_steps': SETTLE,
+                   'parallelism': f'dp{world}' if world > 1 else 'single', 'ranks_seen': ranks_seen,
+                   'backend': ('rccl (torch.distributed nccl)' if backend_used == 'nccl' else
+                               f'{backend_used} [REHEARSAL: not a reportable number]') if backend_used else None,
+                   'settle_steps': SETTLE,
                    'loss_after_timed_steps': LAST_LOSS.get(args.batch_size)},
     }
     if world > 1:

@@ -73,3 +73,25 @@ def evaluate(u_repr: torch.Tensor, i_repr: torch.Tensor, exclude_dense: np.ndarr
         out[f'recall@{k}'] = recall_at_k(y, idx[:, :kk])
         out[f'precision@{k}'] = precision_at_k(y, idx[:, :kk])
     return out
+
+
+def group_metrics(per_user: dict, group_name: str, labels) -> dict:
+    """eval/eval.py:106-119 (``_calculate_group_metrics``): the per-user metric arrays restricted to the users of each
+    label of one categorical user feature; string labels are lower-cased (:112-113). ``per_user``: {'ndcg@10': array[Bu], ...}
+    as ``evaluate`` returns them; ``labels``: one label per user of the batch, in batch order. Keys follow rmet's flattening
+    '{group}_{label}/{metric}' (rmet is absent offline: the key layout is PARITY UNPINNED; the values are the same metric
+    functions applied to a row subset)."""
+    labels = np.array([lbl.lower() if isinstance(lbl, str) else lbl for lbl in labels])
+    out = {}
+    for lbl in sorted(set(labels.tolist())):
+        sel = np.flatnonzero(labels == lbl)
+        for k, v in per_user.items():
+            if '@' in k and not k.startswith('topk'):
+                out[f'{group_name}_{lbl}/{k}'] = np.asarray(v)[sel]
+    return out
+
+
+def natural_sorted(keys):
+    """``natsorted(keys)`` of eval/eval.py:160 restated (natsort's default algorithm: runs of digits compare as integers)."""
+    import re
+    return sorted(keys, key=lambda s: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s)])

@@ -12,6 +12,8 @@ dense-logits entry point for callers that already hold a score matrix.
 """
 from __future__ import annotations
 
+import logging
+import re
 from collections import defaultdict
 from typing import Optional, Sequence
 
@@ -24,9 +26,31 @@ from . import ops
 SUPPORTED_METRICS = ('ndcg', 'precision', 'recall', 'f_score', 'hitrate', 'coverage')
 
 
+RANK_METRIC_MAX_KS = 8            # cut-offs per sbr_rank_metrics launch (METRIC_MAX_KS in csrc/topk.hip)
+
+
 class _Cfg:
-    def __init__(self, top_k=(1, 3, 5, 10, 20, 50, 100), metrics=SUPPORTED_METRICS, calculate_std=True):
+    """The fields of the reference's EvalConfig (data/config_classes.py:183-198) with its defaults."""
+
+    def __init__(self, top_k=(1, 3, 5, 10, 20, 50, 100), metrics=SUPPORTED_METRICS, calculate_std=True,
+                 calculate_group_metrics=False, user_group_features=None):
         self.top_k, self.metrics, self.calculate_std = list(top_k), list(metrics), calculate_std
+        self.calculate_group_metrics, self.user_group_features = calculate_group_metrics, user_group_features
+
+
+def natural_key(s: str):
+    """Sort key of ``natsorted`` (eval/eval.py:160; natsort's default: unsigned integers inside a string compare as numbers,
+    so 'ndcg@3' < 'ndcg@10' < 'ndcg@10_std'). natsort itself is not a dependency of this package."""
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s)]
+
+
+def _cfg_get(cfg, name, default=None):
+    return cfg.get(name, default) if isinstance(cfg, dict) else getattr(cfg, name, default)
+
+
+def _is_categorical(feature) -> bool:
+    t = getattr(getattr(feature, 'feature_definition', None), 'type', None)
+    return str(getattr(t, 'value', t)).lower() == 'categorical'
 
 
 def _csr_to_device(m: sp.spmatrix, device):
@@ -48,11 +72,40 @@ class FullEvaluator:
             raise ValueError(f'Metric(s) {invalid} are not supported. Select metrics from {SUPPORTED_METRICS}.')
         self._ks = sorted(set(int(k) for k in self.config.top_k))
         self._labels_dev = None
+        self._user_features = self._determine_user_features()
+        self._group_maps = {}            # feature name -> (int32 id -> category map on the device, labels)
+        self._warned = False
         self._reset()
+
+    def _determine_user_features(self):
+        """eval/eval.py:74-92: the categorical user features for which group-wise metrics are calculated (None: no groups)."""
+        if not _cfg_get(self.config, 'calculate_group_metrics', False):
+            return None
+        ds = self.dataset
+        feats = getattr(ds, 'user_features', None)
+        if ds is None or feats is None:
+            raise ValueError('calculate_group_metrics needs the dataset (its categorical user features define the groups)')
+        wanted = _cfg_get(self.config, 'user_group_features')
+        if wanted is not None:
+            names = getattr(ds, 'user_feature_names', None)
+            for feature_name in wanted:
+                if feature_name not in (names if names is not None else feats):
+                    raise ValueError(f'Dataset does not contain user feature "{feature_name}". '
+                                     f'Check config whether features are loaded or set to "None" to use'
+                                     f'all available categorical features.')
+                if not _is_categorical(feats[feature_name]):
+                    raise ValueError(f'User feature "{feature_name}" is not categorical.')
+            return list(wanted)
+        defs = getattr(ds, 'user_feature_definitions', None)
+        if defs is not None:
+            return [d.name for d in defs if str(getattr(d.type, 'value', d.type)).lower() == 'categorical']
+        # features the model adds itself (sgd_alg.py:2021-2032) are not feature definitions of the dataset
+        return [n for n, f in feats.items() if _is_categorical(f) and n not in ('user_embedding', 'interactions')]
 
     def _reset(self):
         self._results = defaultdict(list)
         self._topk = []
+        self._groups = defaultdict(list)     # feature name -> per batch int32 category of every evaluated user
 
     def _key(self, metric, k):
         base = f'{metric}@{k}'
@@ -76,8 +129,17 @@ class FullEvaluator:
         """Engine entry point: per-user top-k item positions (int32 [Bu, kmax], kmax >= max(top_k))."""
         kmax = topk_idx.shape[1]
         ks = [k for k in self._ks if k <= kmax]
+        if len(ks) < len(self._ks) and not self._warned:
+            self._warned = True
+            logging.warning(f'FullEvaluator: cut-offs {[k for k in self._ks if k > kmax]} exceed the {kmax} ranked items per user '
+                            f'(catalogue of the split or the scorer\'s list length); their metrics are not reported')
         indptr, indices = self._labels(topk_idx.device)
-        m = ops.rank_metrics(topk_idx.contiguous(), u_idxs.long().contiguous(), indptr, indices, ks)   # [3, n_ks, Bu]
+        topk_idx, u_long = topk_idx.contiguous(), u_idxs.long().contiguous()
+        # [3, n_ks, Bu]; the kernel takes up to RANK_METRIC_MAX_KS cut-offs per launch
+        m = torch.cat([ops.rank_metrics(topk_idx, u_long, indptr, indices, ks[c:c + RANK_METRIC_MAX_KS])
+                       for c in range(0, len(ks), RANK_METRIC_MAX_KS)], dim=1) if ks else None
+        for name in (self._user_features or ()):
+            self._groups[name].append(self._group_map(name, topk_idx.device)[0][u_long])
         for qi, k in enumerate(ks):
             nd, rc, pr = m[0, qi], m[1, qi], m[2, qi]
             if 'ndcg' in self.config.metrics:
@@ -93,6 +155,23 @@ class FullEvaluator:
                 self._results[self._key('f_score', k)].append(torch.where(den > 0, 2 * pr * rc / den.clamp_min(1e-30), den))
         if 'coverage' in self.config.metrics:
             self._topk.append(topk_idx)
+
+    def _group_map(self, name, device):
+        """Resident ``user id -> category`` map of one categorical user feature (replaces the per-batch host lookup
+        ``user_feature[u_idxs]`` + ``get_labels`` of eval/eval.py:110-113) and the group labels (lower-cased strings)."""
+        got = self._group_maps.get(name)
+        if got is None or got[0].device != torch.device(device):
+            f = self.dataset.user_features[name]
+            vals = np.asarray(f.values).astype(np.int64).reshape(-1)
+            ids = np.asarray(getattr(f, '_indices', np.arange(len(vals)))).astype(np.int64)
+            cat = np.full(int(ids.max()) + 1 if len(ids) else 0, -1, dtype=np.int32)
+            cat[ids] = vals
+            uniq = getattr(f, 'unique_values', None)
+            n_cat = int(vals.max()) + 1 if len(vals) else 0
+            labels = [uniq[c] if uniq is not None and c < len(uniq) else c for c in range(n_cat)]
+            labels = [lbl.lower() if isinstance(lbl, str) else lbl for lbl in labels]
+            got = self._group_maps[name] = (torch.from_numpy(cat).to(device), labels)
+        return got
 
     def eval_batch(self, u_idxs: torch.Tensor, logits: torch.Tensor, y_true: torch.Tensor = None):
         """Reference entry point (eval.py:121-138): dense [Bu, I_s] logits (already masked). ``y_true`` is ignored when the
@@ -118,8 +197,24 @@ class FullEvaluator:
             raw = {k: stacked[i] for i, k in enumerate(keys)}
         else:
             raw = {}
+        # group-wise metrics (eval/eval.py:106-119): the same per-user values, restricted to the users of each category of
+        # each group feature. Key layout '{evaluator/}{feature}_{label}/{metric}@{k}' as rmet.calculate_for_feature
+        # flattens it — rmet is absent offline, so the key layout is parity-unpinned (the values are not: a group's array is
+        # the overall array under a mask).
+        for name in (self._user_features or ()):
+            if not self._groups[name] or not raw:
+                continue
+            cats = torch.cat(self._groups[name]).cpu().numpy()
+            labels = self._group_maps[name][1]
+            prefix = f'{self.name}/' if self.name else ''
+            for c in np.unique(cats):
+                if c < 0:
+                    raise KeyError(f'user without a value of group feature "{name}"')
+                sel = cats == c
+                for k in keys:
+                    raw[f'{prefix}{name}_{labels[c]}/{k[len(prefix):]}'] = raw[k][sel]
         metrics = {k: float(v.mean()) for k, v in raw.items()}
-        if getattr(self.config, 'calculate_std', False):
+        if _cfg_get(self.config, 'calculate_std', False):
             metrics.update({f'{k}_std': float(v.std()) for k, v in raw.items()})
         if self._topk:
             top = torch.cat(self._topk)
@@ -133,7 +228,7 @@ class FullEvaluator:
                     seen = torch.zeros(max(int(n_items), int(ids.max()) + 1 if ids.numel() else 1), dtype=torch.bool, device=top.device)
                     seen[ids] = True
                     metrics[self._key('coverage', k)] = int(seen.sum()) / n_items
-        metrics = {k: metrics[k] for k in sorted(metrics)}
+        metrics = {k: metrics[k] for k in sorted(metrics, key=natural_key)}      # natsorted (eval/eval.py:160)
         self._reset()
         return (metrics, raw) if return_raw_results else metrics
 

@@ -28,7 +28,10 @@ def _type_name(t) -> str:
 class HostFeature:
     """Processed feature values + index map, mirroring data/Feature.py. ``kind`` is one of KINDS."""
 
-    def __init__(self, name: str, kind: str, values, indices: Optional[np.ndarray] = None, n_categories: int = None):
+    def __init__(self, name: str, kind: str, values, indices: Optional[np.ndarray] = None, n_categories: int = None,
+                 unique_values: Optional[list] = None):
+        """``unique_values`` (categorical): the sorted raw values whose positions are the integer categories
+        (data/Feature.py:209-218) — what ``get_labels`` maps back to; evaluation groups are named after them."""
         assert kind in KINDS
         ftype = {'dense': 'vector', 'csr': 'vector', 'categorical': 'categorical', 'tag': 'tag'}[kind]
         self.feature_definition = SimpleNamespace(name=name, type=ftype)
@@ -49,6 +52,10 @@ class HostFeature:
             self._dim = 0
         self._n_categories = n_categories if n_categories is not None else (
             int(values.max()) + 1 if kind == 'categorical' and n > 0 else None)
+        self._unique_values = list(unique_values) if unique_values is not None else None
+        if self._unique_values is not None and kind == 'categorical' and self._n_categories is not None \
+                and len(self._unique_values) != self._n_categories:
+            raise ValueError(f'{len(self._unique_values)} unique values for {self._n_categories} categories')
 
     @property
     def values(self):
@@ -67,6 +74,21 @@ class HostFeature:
         if self.kind != 'categorical':
             raise TypeError('Only categorical features support "n_unique_categories"')
         return self._n_categories
+
+    @property
+    def unique_values(self):
+        if self.kind not in ('categorical', 'tag'):
+            raise TypeError('Only categorical and tag features support "unique_values"')
+        if self._unique_values is None:
+            return list(range(self._n_categories if self.kind == 'categorical' else self._dim))
+        return self._unique_values
+
+    def get_labels(self, values):
+        """data/Feature.py:126-128: integer categories -> raw labels."""
+        if self.kind != 'categorical':
+            raise TypeError('Only categorical features support "get_labels"')
+        uniq = self.unique_values
+        return np.array([uniq[int(v)] for v in np.asarray(values).reshape(-1)])
 
     def __len__(self):
         return self._n_values

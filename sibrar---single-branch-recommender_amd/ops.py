@@ -105,14 +105,30 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None, out=None):
 
 
 _TN_WS = {}
+# Workspaces that were outgrown. Their device addresses are baked into every hipGraph captured while they were current
+# (engine.FusedTrainStep), so they are never handed back to the caching allocator: a captured step keeps writing its split-K
+# slabs into the block it was captured with, and nothing else can be placed there. Growth is geometric, so the retired blocks
+# together are smaller than the current one.
+_WS_RETIRED = []
+WS_GENERATION = 0                 # bumped on every workspace reallocation (tests; diagnostics)
+
+
+def _grow(table, key, need, make):
+    global WS_GENERATION
+    old = table.get(key)
+    if old is not None:
+        _WS_RETIRED.append(old)
+        need = max(need, 2 * old.numel())
+    table[key] = ws = make(need)
+    WS_GENERATION += 1
+    return ws
 
 
 def _tn_workspace(device, nbytes):
     """Grow-only scratch for the split-K slabs (one per device; reused by every dW product of a step)."""
     ws = _TN_WS.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(max(nbytes // 4, 1 << 20), device=device, dtype=torch.float32)
-        _TN_WS[device] = ws
+        ws = _grow(_TN_WS, device, max((nbytes + 3) // 4, 1 << 20), lambda n: torch.empty(n, device=device, dtype=torch.float32))
     return ws
 
 
@@ -441,7 +457,7 @@ def _infonce_ws(device, N, D):
     need = lib().sbr_infonce_gemm_workspace(N, D)
     ws = _INFONCE_WS.get(device)
     if ws is None or ws.numel() < need:
-        ws = _INFONCE_WS[device] = torch.empty(need, device=device, dtype=torch.uint8)
+        ws = _grow(_INFONCE_WS, device, need, lambda n: torch.empty(n, device=device, dtype=torch.uint8))
     return ws
 
 

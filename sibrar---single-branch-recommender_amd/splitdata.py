@@ -119,7 +119,7 @@ def build_feature(fd: SimpleNamespace, raw_values, indices, reference_values=Non
         ids = np.array([vmap[v] for v in raw], dtype=np.int64)
         if fd.preprocessing == 'one_hot':
             return HostFeature(fd.name, 'dense', np.eye(len(uniq), dtype=np.float32)[ids], indices)
-        return HostFeature(fd.name, 'categorical', ids, indices, n_categories=len(uniq))
+        return HostFeature(fd.name, 'categorical', ids, indices, n_categories=len(uniq), unique_values=uniq)
     if fd.type == 'tag':
         if fd.tag_split_sep is None:
             raise ValueError(f'For tag feature "{fd.name}" a separator (tag_split_sep) for the individual has to be provided. '

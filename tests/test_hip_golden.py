@@ -588,22 +588,19 @@ def test_two_rank_data_parallel_rehearsal_on_one_gpu():
     The replicas' parameters must agree exactly after the run and training must have made progress."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ, SBR_DIST_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '20', '--warmup', '3',
-           '--no-b256']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_PORT')}
+    env['SBR_DIST_BACKEND'] = 'gloo'
+    # no external launcher: `bench.py --gpus 2` starts its two ranks itself (bench.launch_ranks)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '20', '--warmup', '3', '--no-b256']
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2'
+    assert out['config']['ranks_seen'] == 2 and out['config']['backend'].startswith('gloo')
     assert out['config']['replica_param_checksum_spread'] == 0.0
     assert 'all-gather' in out['config']['user_table_gradient_exchange']
     assert 0.0 < out['config']['loss_after_timed_steps'] < 2.45          # ln(11) = 2.40 at initialisation, falling
@@ -900,3 +897,64 @@ def test_fused_step_matches_module_path_on_config_variants(variant, user_entity)
     for k in sd0:
         if k not in skip:
             close(sd1[k].cpu(), sd0[k].cpu(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_workspace_regrowth_after_capture_does_not_corrupt_replays():
+    """The split-K / InfoNCE scratch buffers are shared by every launch of a process and grow on demand, but their addresses
+    are baked into captured step graphs. A later, larger product (another model, an autograd-path call, a new padded
+    signature) outgrows the buffer: the old block must stay allocated — a replay that wrote its slabs into memory the caching
+    allocator had handed to somebody else would corrupt that tensor (and read back garbage itself). Capture small, outgrow
+    the workspace, put a canary where the allocator would have recycled the block, replay: trajectory == plain launches and
+    the canary is intact."""
+    import sibrar_amd as S
+    ds = S.SyntheticDataset(300, 200, 6000, item_dense={'text': 40}, seed=3, n_negative_samples=3)
+    cfg = {'shared_common_dim': 32, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+           'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
+                    'single_branch_hidden_layers': [32], 'preference_hidden_layers': [], 'common_modality_dim': 32}}
+    rng0 = np.random.default_rng(9)
+    batches = []
+    for _ in range(10):
+        labels = torch.zeros(64, 4, dtype=torch.float64)
+        labels[:, 0] = 1
+        batches.append((torch.from_numpy(rng0.integers(0, ds.n_users, size=64)), torch.from_numpy(rng0.integers(0, ds.n_items, size=(64, 4))),
+                        labels))
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
+        net.train()
+        opt = S.FusedOptimizer(net, 'adamw', lr=1e-2, weight_decay=1e-2)
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=3)
+        fused = S.FusedTrainStep(net, loss, opt, use_graph=use_graph)
+        losses = []
+        canary = None
+        for s_, b in enumerate(batches):
+            if s_ == 6 and use_graph:
+                assert fused.n_replays > 0
+                dev = torch.device(DEV, torch.cuda.current_device())
+                old = S.ops._TN_WS[next(iter(S.ops._TN_WS))]
+                gen = S.ops.WS_GENERATION
+                # a dW product whose slabs need far more than the current workspace: [R, 512]^T [R, 512] over 200k rows
+                R = 200_000
+                big = S.ops.matmul_tn(torch.ones(R, 512, device=DEV), torch.ones(R, 512, device=DEV))
+                assert S.ops.WS_GENERATION > gen, 'the product did not outgrow the workspace: enlarge R'
+                assert float(big[0, 0]) == R
+                del big
+                torch.cuda.synchronize()
+                # whatever the allocator hands out next must not be the retired block
+                canary = [torch.full((old.numel(),), 7.0, device=DEV) for _ in range(3)]
+                assert all(c.data_ptr() != old.data_ptr() for c in canary)
+            losses.append(torch.stack(fused.step(*b)).cpu())
+        if canary is not None:
+            torch.cuda.synchronize()
+            assert all(bool((c == 7.0).all()) for c in canary)
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+        fused.close()
+    for s_, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
+        close(b, a, what=f'losses step {s_}', rtol=1e-6, atol=1e-9)
+    skip = set(bn_shadowed_biases(runs[0][1].keys())) | {'item_embedding_module.sb_net.1.bias'}
+    for k in runs[0][1]:
+        if k not in skip:
+            close(runs[1][1][k].double(), runs[0][1][k].double(), what=k, rtol=1e-4, atol=1e-6, norm_rtol=1e-3)
