@@ -258,7 +258,7 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
             'sharding': f'items/{world}',
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_MFMA_F16, 4), 'traffic': None,
-                         'kernel': 'score_topk_f16_wide_kernel' if i16.shape[1] <= 128 else 'score_topk_f16_kernel',
+                         'kernel': 'score_topk_f16_t_kernel',
                          'avg_launch_ms': round(avg_ms, 4)}}
 
 

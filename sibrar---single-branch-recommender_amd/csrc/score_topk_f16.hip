@@ -818,6 +818,501 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
   }
 }
 
+// =====================================================================================================================
+// Transposed kernel (D <= 128, round 2): users on the LANES, items in the accumulator REGISTERS.
+//
+// The wide kernel above computes S = U x I^T tiles: a lane holds one item column of 16 user rows, so a row's candidates are
+// spread over 32 lanes and every append needs a wave ballot, prefix counts and per-row fill bookkeeping (178 cycles per
+// candidate block, 16 + 16 threshold / fill registers per 32-user tile, scalar branch ladders over 64 ballots per tile).
+// Swapping the MFMA operands (A = item fragment, B = user fragment: the LDS image and the register fragments are the same
+// bytes, the operands of v_mfma_f32_32x32x16_f16 trade places) yields S^T tiles: lane (u, h) holds, for ONE user u of the
+// 32-user tile, the scores of the 16 items (r & 3) + 8 (r >> 2) + 4 h of every 32-item tile. Top-k state becomes lane-local:
+//   * one threshold and one fill count per lane and user tile (4 VGPRs instead of 40);
+//   * a candidate is appended by its own lane to its own buffer half (global workspace, S4_CAPH entries per (user, h)) with a
+//     fire-and-forget store at base + fill: no ballot, no prefix count, no cross-lane traffic;
+//   * only compaction is cooperative: the wave loads both halves of a user's buffer (<= 128 entries, two per lane), selects
+//     the k best by bitwise binary search over ballot counts (s4_select), stores them back into half 0 and hands the new
+//     threshold to the user's two lanes.
+// Prefilter pass. A streaming top-k meets most of its candidates early (k ln(I / k) ~ 160 per user with perfect thresholds,
+// 344 measured with thresholds refreshed only at compaction; two thirds of them in the first 10 % of the catalogue). The
+// kernel therefore first streams a PREFIX of the catalogue (n_pre tiles, ~8 %) keeping only a running maximum per
+// accumulator register (64 item classes per user: one v_max per score, no candidates). The k-th largest of a user's 64 class
+// maxima is the score of an actual item with at least k - 1 distinct items above it: a safe lower bound of the user's final
+// k-th best (its expected rank among the prefix items is ~24 for k = 20). The main pass then starts from tile 0 with that
+// bound as threshold (inclusive: the bounding items themselves must come back), so the prefix contributes ~24 candidates per
+// user instead of ~170. Exclusions and the catalogue end are honoured in both passes; results are exact and ordered by
+// (score desc, item index asc) like every other path.
+// =====================================================================================================================
+#define S4_WAVES 7
+#define S4_ROWS (S4_WAVES * 64)
+#define S4_THREADS ((S4_WAVES + 1) * 64)
+#define S4_CAPH 64                       // candidate buffer entries per (user, lane half) in the global workspace
+
+// All 64 lanes of the owning wave: the k best of the n0 + n1 (each <= 64, wave-uniform) entries of a user's two buffer halves
+// (lane l holds b0[l] and b1[l]) are stored to b0[0 .. k), unsorted; returns the k-th best score (-inf and nothing moved while
+// fewer than k entries exist). e / keep: the lane's two entries and whether they survived.
+__device__ __forceinline__ float s4_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane,
+                                           unsigned long long e[2], bool keep[2]) {
+  const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
+  // written and read by this wave only: same-CU vector memory path, in order (see s3_select)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  e[0] = lane < n0 ? b0[lane] : 0ull;
+  e[1] = lane < n1 ? b1[lane] : 0ull;
+  keep[0] = lane < n0;
+  keep[1] = lane < n1;
+  if (n0 + n1 < k) return -INFINITY;
+  const unsigned int h0 = (unsigned int)(e[0] >> 32), h1 = (unsigned int)(e[1] >> 32);
+  unsigned int T = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    const int cnt = __popcll(__ballot(h0 >= trial)) + __popcll(__ballot(h1 >= trial));
+    T = cnt >= k ? trial : T;
+  }
+  unsigned long long C = (unsigned long long)T << 32;
+  const int c_ge = __popcll(__ballot(h0 >= T)) + __popcll(__ballot(h1 >= T));
+  if (c_ge != k) {
+    const int need = k - (__popcll(__ballot(h0 > T)) + __popcll(__ballot(h1 > T)));
+    const unsigned int l0 = (unsigned int)e[0], l1 = (unsigned int)e[1];
+    unsigned int Lw = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = Lw | (1u << bit);
+      const int cnt = __popcll(__ballot(h0 == T && l0 >= trial)) + __popcll(__ballot(h1 == T && l1 >= trial));
+      Lw = cnt >= need ? trial : Lw;
+    }
+    C |= (unsigned long long)Lw;
+  }
+  keep[0] = e[0] >= C;
+  keep[1] = e[1] >= C;
+  const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+  const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m0, 0u));
+  const int p1 = __popcll(m0) + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m1, 0u));
+  if (keep[0]) b0[p0] = e[0];
+  if (keep[1]) b0[p1] = e[1];
+  return st_key2f(T);
+}
+
+template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations; PRE: prefix pass compiled in
+__global__ __launch_bounds__(S4_THREADS, 2) void score_topk_f16_t_kernel(
+    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
+    const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int n_pre,
+    float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ gbuf,
+    unsigned long long* __restrict__ dbgbuf) {
+  constexpr int D = KS * 16;
+  constexpr int ST_TILE = 32 * NJ;
+  constexpr int LIMIT = S4_CAPH - 16 * NJ;                 // a tile adds at most 16 NJ entries to a (user, half) buffer
+  constexpr int ROWB = D * 2;
+  constexpr int TILEB = ST_TILE * ROWB;
+  constexpr int CPR = D / 8;
+  constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);
+  constexpr int PER_T = (ST_TILE * CPR) / 64;
+  constexpr int LFL0 = NS > 2 ? NS - 2 : 1;
+  constexpr int LFL = LFL0 * PER_T <= 63 ? LFL0 : 63 / PER_T;
+  static_assert(LFL >= 1 && LFL * PER_T <= 63, "vmcnt field");
+  static_assert(LIMIT >= 32, "k <= 32 entries must fit below the compaction limit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB);                            // [S4_WAVES*64][2]
+  int* enx = reinterpret_cast<int*>(exw + S4_WAVES * 64 * 2);                                        // [S4_WAVES*64]
+  lds_int* full_lds = (lds_int*)(enx + S4_WAVES * 64);
+  lds_int* free_lds = full_lds + NS;
+  lds_int* enx_lds = (lds_int*)enx;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const long row0 = (long)blockIdx.x * S4_ROWS;
+  const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
+  const int n_virt = n_pre + n_tiles;                      // tile sequence: prefix tiles 0 .. n_pre - 1, then all tiles
+
+  if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
+  __syncthreads();                                         // the only workgroup barrier of the kernel
+
+  if (wave == S4_WAVES) {
+    // ---------------------------------------------- loader wave ------------------------------------------------------
+    for (int v = 0; v < n_virt; ++v) {
+      const int slot = v % NS;
+      if (v >= NS) {
+        const int need = S4_WAVES * (v / NS);
+        while (st_peek(free_lds + slot) < need) __builtin_amdgcn_s_sleep(1);
+      }
+      const int j0 = (v < n_pre ? v : v - n_pre) * ST_TILE;
+      unsigned char* dst = smem + slot * TILEB;
+#pragma unroll
+      for (int q = 0; q < PER_T; ++q) {
+        const int P = q * 64 + lane;
+        const int i = P / CPR, cp = P % CPR;
+        int gi = j0 + i;
+        gi = gi < I ? gi : I - 1;
+        const _Float16* src = It + (long)gi * D + ((cp ^ (i & SWZ)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+      }
+      if (v >= LFL) {
+        st_wait_vmcnt<LFL * PER_T>();
+        st_wave_fence();
+        *(volatile lds_int*)(full_lds + (v - LFL) % NS) = v - LFL + 1;
+      }
+    }
+    st_wait_vmcnt<0>();
+    st_wave_fence();
+    for (int v = (n_virt > LFL ? n_virt - LFL : 0); v < n_virt; ++v)
+      *(volatile lds_int*)(full_lds + v % NS) = v + 1;
+    return;
+  }
+
+  // ------------------------------------------------ consumer waves ------------------------------------------------------
+  // B-operand fragments of the wave's two 32-user tiles: user 64 * wave + 32 * mt + l31, k = 16 s + 8 half + j
+  f16x8 ufrag[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long r = row0 + wave * 64 + mt * 32 + l31;
+    const long ur = r < Bu ? r : Bu - 1;
+    const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ufrag[mt][s] = src[2 * s + half];
+  }
+  unsigned long long* wgb = gbuf + (row0 + (long)wave * 64) * (2 * S4_CAPH);      // wave-uniform: buffers of the wave's 64 users
+  exw[2 * t] = 0u;
+  exw[2 * t + 1] = 0u;
+  // exclusion cursor: lane L walks the sorted CSR row of user 64 * wave + L (user tile L >> 5, user column L & 31) in step with
+  // the item tiles; e0 = next excluded item, the one after it sits in LDS (see the first kernel). lo0: restart point of pass 2.
+  const long my_row = row0 + wave * 64 + lane;
+  long eidx = 0, eend = 0, lo0 = 0;
+  int e0 = 0x7FFFFFFF;
+  {
+    int e1 = 0x7FFFFFFF;
+    if (my_row < Bu && excl_indptr) {
+      const long u = u_idx ? u_idx[my_row] : my_row;
+      long lo = excl_indptr[u];
+      eend = excl_indptr[u + 1];
+      long hi = eend;
+      while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
+      }
+      lo0 = lo;
+      if (lo < eend) e0 = excl_indices[lo];
+      if (lo + 1 < eend) e1 = excl_indices[lo + 1];
+      eidx = lo + 1;
+    }
+    enx[t] = e1;
+  }
+  st_wave_fence();
+  bool e_pending = false;
+  // lane (u, h): threshold and buffer fill of user 32 mt + u, half h (thresholds of the two halves of a user are equal)
+  float thr[2] = {-INFINITY, -INFINITY};
+  int cnt[2] = {0, 0};
+  const unsigned int lane_base = (unsigned int)((l31 * 2 + half) * S4_CAPH * 8);     // + mt * 32 * 2 * S4_CAPH * 8
+
+  unsigned long long t_wait = 0, t_evt = 0, n_evt = 0, n_ins = 0, n_cand = 0, t_cmp = 0, t_issue = 0, t_ladder = 0;
+  const unsigned long long t_begin = DBG != 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_begin = DBG != 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  // one item tile: wait, MFMAs (S^T = I x U^T), slot release, exclusion bits of the tile -> acc, have_ex
+#define S4_TILE_BODY(V)                                                                                                  \
+    const int slot = (V) % NS;                                                                                           \
+    const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;                                       \
+    while (st_peek(full_lds + slot) != (V) + 1) __builtin_amdgcn_s_sleep(1);                                             \
+    st_wave_fence();                                                                                                     \
+    if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;                                                \
+    const unsigned char* cur = smem + slot * TILEB;                                                                      \
+    f32x16 acc[2][2];                                                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                   \
+      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) {                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][nj][r] = 0.f;                                             \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                     \
+      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) {                                                                \
+        const int i = nj * 32 + l31;                                                                                     \
+        const int c = 2 * s + half;                                                                                      \
+        const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));                        \
+        acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, ufrag[0][s], acc[0][nj], 0, 0, 0);                        \
+        acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, ufrag[1][s], acc[1][nj], 0, 0, 0);                        \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(acc[0][0]), "v"(acc[0][NJ - 1]), "v"(acc[1][0]), "v"(acc[1][NJ - 1]) : "memory"); \
+    if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);                                                                \
+    /* exclusions of this tile: item column `col` of the tile, user (L >> 5, L & 31): one bit for the lane that holds that  \
+       accumulator — lane (L & 31) + 32 ((col >> 2) & 1), word L >> 5, bit (col >> 5) * 16 + (col & 3) + 4 ((col & 31) >> 3) */ \
+    const int gbase = item_offset + j0;                                                                                  \
+    bool wrote_ex = false;                                                                                               \
+    for (int round = 0;; ++round) {                                                                                      \
+      const bool take = e0 < gbase + ST_TILE;                                                                            \
+      if (!__ballot(take)) break;                                                                                        \
+      if (e_pending) st_wait_vmcnt<0>();                                                                                 \
+      e_pending = false;                                                                                                 \
+      wrote_ex = true;                                                                                                   \
+      if (take) {                                                                                                        \
+        const int col = e0 - gbase;                                                                                      \
+        const int tgt = wave * 64 + l31 + 32 * ((col >> 2) & 1);                                                         \
+        atomicOr(&exw[2 * tgt + half], 1u << ((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3)));                     \
+        st_wave_fence();                                                                                                 \
+        e0 = enx_lds[t];                                                                                                 \
+        ++eidx;                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+        if (eidx < eend) {                                                                                               \
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(excl_indices + eidx),         \
+                                           (__attribute__((address_space(3))) void*)(enx + wave * 64), 4, 0, 0);         \
+        } else {                                                                                                         \
+          enx_lds[t] = 0x7FFFFFFF;                                                                                       \
+          st_wave_fence();                                                                                               \
+        }                                                                                                                \
+      }                                                                                                                  \
+      e_pending = true;                                                                                                  \
+    }                                                                                                                    \
+    const bool have_ex = __ballot(wrote_ex) != 0ull;
+
+  // ---- pass 1: prefix tiles, running maximum per accumulator register (item class) ----
+  if (PRE && n_pre > 0) {
+    f32x16 cm[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[mt][nj][r] = -INFINITY;
+      }
+    }
+    for (int v = 0; v < n_pre; ++v) {
+      const int j0 = v * ST_TILE;
+      S4_TILE_BODY(v)
+      if (have_ex) {                                       // excluded scores must not raise a class maximum
+        st_wave_fence();
+        const unsigned int ex0 = exw[2 * t], ex1 = exw[2 * t + 1];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[0][nj][r] = ((ex0 >> (nj * 16 + r)) & 1u) ? -INFINITY : acc[0][nj][r];
+            acc[1][nj][r] = ((ex1 >> (nj * 16 + r)) & 1u) ? -INFINITY : acc[1][nj][r];
+          }
+        }
+        exw[2 * t] = 0u;
+        exw[2 * t + 1] = 0u;
+        st_wave_fence();
+      }
+      if (j0 + ST_TILE > I) {                              // catalogue end inside the tile: padded columns do not count
+        const int lim = I - j0 - 4 * half;
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool in = nj * 32 + (r & 3) + 8 * (r >> 2) < lim;
+            acc[0][nj][r] = in ? acc[0][nj][r] : -INFINITY;
+            acc[1][nj][r] = in ? acc[1][nj][r] : -INFINITY;
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cm[mt][nj][r] = fmaxf(cm[mt][nj][r], acc[mt][nj][r]);
+        }
+      }
+    }
+    // k-th largest of each user's 32 NJ class maxima (16 NJ in each of its two lanes): bitwise binary search on the ordered
+    // keys, every lane pair for its own user. The threshold admits scores EQUAL to the bound (its items are not in any buffer).
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      unsigned int T = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = T | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c += st_f2key(cm[mt][nj][r]) >= trial;
+        }
+        c += __shfl_xor(c, 32, 64);
+        T = c >= k ? trial : T;
+      }
+      // T = 0x007FFFFF is the key of -inf (fewer than k finite classes): no bound
+      thr[mt] = T > 0x007FFFFFu ? st_key2f(T - 1u) : -INFINITY;
+    }
+    // restart the exclusion cursor for the main pass
+    if (excl_indptr) st_wait_vmcnt<0>();
+    e_pending = false;
+    e0 = 0x7FFFFFFF;
+    int e1 = 0x7FFFFFFF;
+    if (lo0 < eend) e0 = excl_indices[lo0];
+    if (lo0 + 1 < eend) e1 = excl_indices[lo0 + 1];
+    eidx = lo0 + 1;
+    enx_lds[t] = e1;
+    st_wave_fence();
+  }
+
+  // ---- pass 2: all tiles, lane-local threshold filter and appends ----
+  for (int tl = 0; tl < n_tiles; ++tl) {
+    if (__ballot(cnt[0] > LIMIT || cnt[1] > LIMIT)) {
+      // ---- maintenance (cold): compact the users with a half above LIMIT so that this tile's appends cannot overflow
+      const unsigned long long tm0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        unsigned long long need = __ballot(cnt[mt] > LIMIT);
+        need = (need | (need >> 32)) & 0xFFFFFFFFull;
+        while (need) {
+          const int u = __ffsll((long long)need) - 1;
+          need &= need - 1ull;
+          const int n0 = __builtin_amdgcn_readlane(cnt[mt], u), n1 = __builtin_amdgcn_readlane(cnt[mt], u + 32);
+          unsigned long long* b0 = wgb + (long)(mt * 32 + u) * (2 * S4_CAPH);
+          unsigned long long e[2];
+          bool kp[2];
+          const float nt = s4_select(b0, b0 + S4_CAPH, n0, n1, k, lane, e, kp);
+          if (n0 + n1 >= k && l31 == u) {
+            thr[mt] = nt;
+            cnt[mt] = half ? 0 : k;
+          }
+          if constexpr (DBG == 4) ++n_ins;
+        }
+      }
+      if constexpr (DBG == 4) t_cmp += __builtin_amdgcn_s_memtime() - tm0;
+    }
+    const int j0 = tl * ST_TILE;
+    const int vseq = n_pre + tl;
+    const unsigned long long ti0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+    S4_TILE_BODY(vseq)
+    const unsigned long long ti1 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+    if constexpr (DBG == 4) t_issue += ti1 - ti0 - (__builtin_amdgcn_s_memtime() - ti1);
+    if constexpr (DBG == 1) {
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][NJ - 1]), "v"(acc[1][0]), "v"(acc[1][NJ - 1]));
+      continue;
+    }
+    unsigned int ex[2] = {0u, 0u};
+    if (have_ex) { st_wave_fence(); ex[0] = exw[2 * t]; ex[1] = exw[2 * t + 1]; }
+    if (j0 + ST_TILE > I) {                                // catalogue end inside the (last) tile: padded columns never qualify
+      const int lim = I - j0 - 4 * half;                   // item (r & 3) + 8 (r >> 2) + 32 nj of this lane exists iff < lim
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool in = nj * 32 + (r & 3) + 8 * (r >> 2) < lim;
+          acc[0][nj][r] = in ? acc[0][nj][r] : -INFINITY;
+          acc[1][nj][r] = in ? acc[1][nj][r] : -INFINITY;
+        }
+      }
+    }
+    const unsigned int item_lane = 0xFFFFFFFFu - (unsigned int)(item_offset + j0 + 4 * half);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      char* bufp = reinterpret_cast<char*>(wgb) + mt * (32 * 2 * S4_CAPH * 8);
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // common path per FOUR accumulator registers: four v_cmp into SGPR pairs issued back to back, three s_or, one scalar
+          // branch (a v_cmp -> branch pair per register serialises on the compare's latency: 27 cycles per register, 0.6 ms
+          // per pass, measured with the compare-only ablation)
+          unsigned long long bq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[q] = __ballot(acc[mt][nj][4 * g + q] > thr[mt]);
+          if constexpr (DBG == 2) { if (bq[0] | bq[1] | bq[2] | bq[3]) asm volatile("s_nop 0"); continue; }
+          if (bq[0] | bq[1] | bq[2] | bq[3]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = 4 * g + q;
+              if (bq[q]) {
+                const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+                // everything below hangs off values pinned inside the branch (hipcc otherwise if-converts the block and
+                // evaluates exclusion / key arithmetic for every register of every tile)
+                float v = acc[mt][nj][r];
+                unsigned int exv = ex[mt];
+                asm volatile("" : "+v"(v), "+v"(exv));
+                const int C = nj * 32 + (r & 3) + 8 * (r >> 2);          // compile-time after unrolling
+                const bool cand = (v > thr[mt]) && !((exv >> (nj * 16 + r)) & 1u);
+                if (cand) {
+                  const unsigned long long key = ((unsigned long long)st_f2key(v) << 32) | (unsigned long long)(item_lane - (unsigned int)C);
+                  *reinterpret_cast<unsigned long long*>(bufp + lane_base + ((unsigned int)cnt[mt] << 3)) = key;
+                  ++cnt[mt];
+                }
+                if constexpr (DBG == 4) { n_cand += __popcll(__ballot(cand)); t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (have_ex) { exw[2 * t] = 0u; exw[2 * t + 1] = 0u; st_wave_fence(); }
+    if constexpr (DBG == 4) t_ladder += __builtin_amdgcn_s_memtime() - ti1;
+  }
+#undef S4_TILE_BODY
+
+  if constexpr (DBG != 0) {
+    if (lane == 0 && dbgbuf) {
+      unsigned long long* d = dbgbuf + ((long)blockIdx.x * S4_WAVES + wave) * 8;
+      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_evt; d[3] = n_cand; d[4] = n_evt | (t_issue << 20); d[5] = n_ins | (t_ladder << 20); d[6] = t_cmp;
+      d[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+    }
+  }
+  // final selection + output of the wave's 64 users: the lane that holds the entry of rank j writes output position j
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    for (int u = 0; u < 32; ++u) {
+      const long ur = row0 + wave * 64 + mt * 32 + u;
+      if (ur >= Bu) break;
+      const int n0 = __builtin_amdgcn_readlane(cnt[mt], u), n1 = __builtin_amdgcn_readlane(cnt[mt], u + 32);
+      unsigned long long* b0 = wgb + (long)(mt * 32 + u) * (2 * S4_CAPH);
+      unsigned long long e[2];
+      bool kp[2];
+      s4_select(b0, b0 + S4_CAPH, n0, n1, k, lane, e, kp);
+      int rk[2] = {0, 0};
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        const int h32 = (int)(e[part] >> 32), l32 = (int)e[part];
+        for (unsigned long long m = __ballot(kp[part]); m; m &= m - 1ull) {
+          const int j = __ffsll((long long)m) - 1;
+          const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(h32, j) << 32) |
+                                        (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(l32, j);
+          rk[0] += kj > e[0];
+          rk[1] += kj > e[1];
+        }
+      }
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        if (kp[part]) {
+          out_val[ur * k + rk[part]] = st_key2f((unsigned int)(e[part] >> 32));
+          out_idx[ur * k + rk[part]] = (int)(0xFFFFFFFFu - (unsigned int)(e[part] & 0xFFFFFFFFull));
+        }
+      }
+      const int n = n0 + n1;
+      if (lane >= n && lane < k) {                           // fewer than k candidates: empty slots behind them
+        out_val[ur * k + lane] = -INFINITY;
+        out_idx[ur * k + lane] = -1;
+      }
+    }
+  }
+}
+
+template <int KS, int NS, int NJ, bool PRE>
+static int s4_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+                     int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
+  const long rows_padded = sbr_cdiv(Bu, S4_ROWS) * (long)S4_ROWS;
+  const long need = rows_padded * 2 * S4_CAPH * 8;
+  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations, 4: cycle stamps
+  SBR_REQUIRE(workspace && workspace_bytes >= need + (dbg != 0 ? sbr_cdiv(Bu, S4_ROWS) * S4_WAVES * 64L : 0L),
+              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", need, workspace_bytes);
+  void* dbg_buf = (char*)workspace + need;
+  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + S4_WAVES * 64 * 12 + 2 * NS * 4 + 16;
+  SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
+  // prefix pass: ~1/12 of the catalogue (whole tiles), skipped for catalogues too short to repay it; SBR_ST_PRE overrides (tiles)
+  const int n_tiles = sbr_cdiv(I, 32 * NJ);
+  int n_pre = n_tiles >= 96 ? n_tiles / 12 : 0;
+  if (getenv("SBR_ST_PRE")) n_pre = atoi(getenv("SBR_ST_PRE"));
+  if (n_pre > n_tiles) n_pre = n_tiles;
+  if (n_pre < 0 || !PRE) n_pre = 0;
+  auto kern = dbg == 1 ? score_topk_f16_t_kernel<KS, NS, NJ, 1, PRE> : (dbg == 2 ? score_topk_f16_t_kernel<KS, NS, NJ, 2, PRE> :
+              (dbg == 4 ? score_topk_f16_t_kernel<KS, NS, NJ, 4, PRE> : score_topk_f16_t_kernel<KS, NS, NJ, 0, PRE>));
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
+    return SBR_ERR_HIP;
+  }
+  kern<<<sbr_cdiv(Bu, S4_ROWS), S4_THREADS, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k,
+                                                      n_pre, out_val, out_idx, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
+  SBR_CHECK_LAUNCH("sbr_score_topk_f16");
+  return SBR_OK;
+}
+
 template <int KS, int NS, int NJ>
 static int s3_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
                      int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
@@ -888,6 +1383,14 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   // D <= 128: the 64-users-per-wave kernel (SBR_SCORER_V1=1 keeps the first kernel for A/B timing). D = 256 stays on the first
   // kernel: two A fragment sets need 128 VGPRs; the wide kernel with 32-item tiles (<16, 6, 1>) spills A fragments to scratch
   // and reloads them inside the MFMA loop — measured 3.90 / 4.28 ms against 3.72 / 3.79 ms on 100k x 25k x 256.
+  if (st_use_wide(D) && !(getenv("SBR_SCORER_V2") && atoi(getenv("SBR_SCORER_V2")) != 0)) {
+    if (D == 128) return s4_launch<8, 6, 2, true>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    return s4_launch<4, 8, 2, true>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+  }
+  // D = 256: the same kernel without the prefix pass (two 16-step user fragment sets + the accumulators leave no room for the
+  // 64 class-maximum registers): 2.50 ms against 3.2 ms of the first kernel on the c5 shard shape (100k x 25k x 256)
+  if (D == 256 && !(getenv("SBR_SCORER_V1") && atoi(getenv("SBR_SCORER_V1")) != 0))
+    return s4_launch<16, 4, 2, false>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
   if (st_use_wide(D)) {
     if (D == 128) return s3_launch<8, 6, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
     return s3_launch<4, 8, 2>(U_f16, I_f16, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);

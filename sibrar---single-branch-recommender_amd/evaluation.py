@@ -238,8 +238,7 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     """eval/eval.py:171-227 (SGD branch :203-222). ``eval_loader`` only has to expose ``dataset`` and ``batch_size``.
 
     The users are scored in engine-sized chunks, not in the loader's batches: per-user results do not depend on the grouping,
-    and the reference's default evaluation batch (256 users) leaves the GPU idle — the fused kernels assign 448 (D <= 128) or 224
-    (D = 256) users to a workgroup and every workgroup streams the whole catalogue, so they want >= 57k users per launch (measured on
+    and the reference's default evaluation batch (256 users) leaves the GPU idle — the fused kernel assigns 448 users to a workgroup and every workgroup streams the whole catalogue, so they want >= 57k users per launch (measured on
     c2, 100k users, first kernel: 975 ms with 256-user batches, 37 ms with 8192, 12 ms in one launch); the fp32 path is bounded by the [chunk, items] score
     matrix it materialises. ``user_chunk`` overrides the choice."""
     dataset = eval_loader.dataset
