@@ -192,6 +192,39 @@ int sbr_bn_train_bwd(const float* dY, const float* Y, const float* X, float* dX,
                      const float* save_mean, const float* save_rstd, float* dWeight, float* dBias, double* ws, int act,
                      void* stream);
 
+/* statistics half of sbr_bn_train_fwd: batch mean / rstd + running-statistics update, no normalising pass (the consumer
+ * normalises on the fly: sbr_bn_score_fwd). */
+int sbr_bn_train_stats(const float* X, long n, int D, float* running_mean, float* running_var, long* num_batches_tracked,
+                       float* save_mean, float* save_rstd, double* ws, float eps, float momentum, void* stream);
+
+/* ---- trailing BatchNorm1d fused with the training scorer (one modality per slot) — algorithms/sgd_alg.py:1834-1837,
+ * 1871-1877 (sb_net's trailing BatchNorm1d, no activation) followed by einsum('be,bce->bc') sgd_alg.py:2114, forward and
+ * autograd: the normalised item representation [B*N, D] and its gradient are never stored (csrc/fused_tail.hip).
+ *   fwd:        logits[b, n] = sum_d U[b, d] * ((Z[s, d] - mean[d]) * rstd[d] * weight[d] + bias[d]),  s = b*N + n
+ *   bwd_stats:  dU[b, :] = sum_n G[b, n] * y[s, :];  ws[0..2D) = column sums of dy and dy * xhat, dy[s, :] = G[s] * U[b, :]
+ *   bwd_apply:  dX = weight * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)); dWeight / dBias of the BatchNorm from ws;
+ *               ws_colsum (17*D doubles, may be NULL): pending column sums of dX (bias gradient of the Linear in front of the
+ *               BatchNorm), completed by sbr_colred_finish.
+ * ws: the BatchNorm's 34*D-double workspace (contract of sbr_bn_train_fwd). D % 4 == 0, D <= 256, 16-byte aligned operands
+ * (sbr_bn_score_supported). */
+int sbr_bn_score_supported(int D);
+int sbr_bn_score_fwd(const float* Z, const float* U, const float* mean, const float* rstd, const float* weight, const float* bias,
+                     float* logits, long B, int N, int D, void* stream);
+int sbr_bn_score_bwd_stats(const float* G, const float* U, const float* Z, float* dU, long B, int N, int D, const float* weight,
+                           const float* bias, const float* save_mean, const float* save_rstd, double* ws, void* stream);
+int sbr_bn_score_bwd_apply(const float* G, const float* U, const float* Z, float* dX, long B, int N, int D, const float* weight,
+                           const float* save_mean, const float* save_rstd, const double* ws, float* dWeight, float* dBias,
+                           double* ws_colsum, void* stream);
+
+/* sbr_act_grad_gather that also accumulates the column sums of dZ (the bias gradient of its layer, modules/polylinear.py:51)
+ * into a column-reduction workspace (17*C doubles, contract of sbr_colsum); sbr_colred_finish turns up to 8 pending
+ * workspaces into float vectors (out[q][c] = sum over the replicas of workspaces[q], replicas re-zeroed) with one launch.
+ * workspaces / outs: HOST arrays of device pointers, widths: HOST array. */
+int sbr_act_grad_colsum_supported(int C);
+int sbr_act_grad_gather_colsum(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz, long n, int C,
+                               int act, double* ws, void* stream);
+int sbr_colred_finish(int count, const void* const* workspaces, const void* const* outs, const int* widths, void* stream);
+
 /* ---- losses ----------------------------------------------------------------------------------------------------------------
  * RecBinaryCrossEntropy / RecBayesianPersonalizedRankingLoss / RecSampledSoftmaxLoss .compute_loss —
  * train/rec_losses.py:43-58, 63-83, 88-113. labels: float64 [B, N] (unused for sampled softmax). scale = 1/count for

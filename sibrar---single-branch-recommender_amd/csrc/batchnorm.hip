@@ -84,12 +84,8 @@ static int grid1d(long total) {
 
 // workspace ws: 34*D doubles (2*D totals + 16 replicas, see sbr_col_reduce in common.h), ZERO on first use; every call
 // leaves the replica part zeroed again (no memset per call)
-extern "C" int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
-                                float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
-                                float* save_rstd, double* ws, float eps, float momentum, int act, void* stream) {
-  SBR_REQUIRE(X && Y && weight && bias && save_mean && save_rstd && ws, "sbr_bn_train_fwd: null operand");
-  SBR_REQUIRE(n >= 1, "sbr_bn_train_fwd: BatchNorm needs at least one row");
-  hipStream_t s = (hipStream_t)stream;
+static int bn_train_stats(const float* X, long n, int D, float* running_mean, float* running_var, long* num_batches_tracked,
+                          float* save_mean, float* save_rstd, double* ws, float eps, float momentum, hipStream_t s) {
   if (sbr_col_reduce_ok(X, D, D)) {
     bn_stats4_kernel<<<sbr_col_reduce_blocks(n, D), 256, 0, s>>>(X, n, D, ws);
   } else {                       // generic path: atomics straight into replica 1
@@ -101,9 +97,31 @@ extern "C" int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const f
   bn_finalize_kernel<<<sbr_cdiv(D, 256), 256, 0, s>>>(ws, n, D, eps, momentum, save_mean, save_rstd, running_mean,
                                                       running_var, num_batches_tracked);
   SBR_CHECK_LAUNCH("sbr_bn_train_fwd/finalize");
+  return SBR_OK;
+}
+
+extern "C" int sbr_bn_train_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
+                                float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
+                                float* save_rstd, double* ws, float eps, float momentum, int act, void* stream) {
+  SBR_REQUIRE(X && Y && weight && bias && save_mean && save_rstd && ws, "sbr_bn_train_fwd: null operand");
+  SBR_REQUIRE(n >= 1, "sbr_bn_train_fwd: BatchNorm needs at least one row");
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = bn_train_stats(X, n, D, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, ws, eps, momentum, s);
+  if (rc != SBR_OK) return rc;
   bn_apply_kernel<<<grid1d(n * D), 256, 0, s>>>(X, Y, n, D, save_mean, save_rstd, weight, bias, act);
   SBR_CHECK_LAUNCH("sbr_bn_train_fwd/apply");
   return SBR_OK;
+}
+
+// statistics half of sbr_bn_train_fwd (batch mean / rstd, running-statistics update) without the normalising pass: the
+// consumer applies the normalisation itself (fused_tail.hip: sbr_bn_score_fwd)
+extern "C" int sbr_bn_train_stats(const float* X, long n, int D, float* running_mean, float* running_var,
+                                  long* num_batches_tracked, float* save_mean, float* save_rstd, double* ws, float eps,
+                                  float momentum, void* stream) {
+  SBR_REQUIRE(X && save_mean && save_rstd && ws, "sbr_bn_train_stats: null operand");
+  SBR_REQUIRE(n >= 1, "sbr_bn_train_stats: BatchNorm needs at least one row");
+  return bn_train_stats(X, n, D, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, ws, eps, momentum,
+                        (hipStream_t)stream);
 }
 
 extern "C" int sbr_bn_eval_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,

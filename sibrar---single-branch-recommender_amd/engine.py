@@ -94,6 +94,12 @@ class _EntityRun:
         self.reg = ent._reg_type != EmbeddingRegularizationType.NoRegularization
         self.tau, self.reg_w = float(cfg.regularization_temperature), float(cfg.regularization_weight)
         self._ws = {}
+        self._cs_ws = {}             # id(linear) -> column-reduction workspace of its folded bias gradient
+        # set by FusedTrainStep for the ITEM side: the trailing BatchNorm is applied inside the scorer (csrc/fused_tail.hip)
+        # whenever a step draws one modality per slot; the normalised representation is then never stored
+        self.fuse_tail = False
+        self.tail = None             # (z, mean, rstd) of the current step when the tail is fused
+        self.fold = os.environ.get('SBR_FOLD_COLSUM', '1') != '0'
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def plan(self, draw: Tuple[np.ndarray, list], pad: bool = False):
@@ -182,7 +188,18 @@ class _EntityRun:
                 self.acts.append((x, z, y, mean, rstd))
             x = y
         self.tb = None
+        self.tail = None
         if self.trailing is not None:
+            if self.fuse_tail and k == 1 and not self.reg and ops.lib().sbr_bn_score_supported(int(x.shape[1])):
+                # statistics only: the scorer normalises on the fly (FusedTrainStep._phase1), nothing else reads the output
+                bn, n_, D_ = self.trailing, x.shape[0], x.shape[1]
+                mean, rstd = a.f32(D_), a.f32(D_)
+                call('sbr_bn_train_stats', ptr(x), n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                     ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
+                self.tail = (x, mean, rstd)
+                self.e = None
+                self.reg_loss = None
+                return None
             y, mean, rstd = self._bn_fwd(self.trailing, x, 0)
             self.tb = (x, y, mean, rstd)
             x = y
@@ -230,44 +247,81 @@ class _EntityRun:
         return dx
 
     # ---- backward ------------------------------------------------------------------------------------------------------
-    def backward(self, dout: torch.Tensor, one_f32: torch.Tensor):
+    def _fold_ws(self, lin, C):
+        ws = self._cs_ws.get(id(lin))
+        if ws is None:
+            ws = self._cs_ws[id(lin)] = ops.new_colsum_ws(lin.weight.device, C)
+        return ws
+
+    def backward(self, dout: torch.Tensor, one_f32: torch.Tensor, tail=None):
+        """``tail`` = (dlogits [B, N], user representations [B, D]) when the trailing BatchNorm was fused into the scorer: the
+        gradient of the normalised representation is dlogits[s] * u[b(s), :] and is never stored."""
         ent, a, st = self.ent, self.a, ops.stream()
         R, k, D = self.R, self.k, self.D
         S = R // k
-        if k == 1:
-            de = dout
+        pending = [] if self.fold else None           # folded bias-gradient column sums, completed by ONE launch at the end
+        last_lin = self.layers[-1] if self.layers else None
+        folded_last = False
+        if tail is not None:
+            dlog, ur = tail
+            z, mean, rstd = self.tail
+            bn = self.trailing
+            d = a.f32(R, D)
+            ws_col = None
+            if pending is not None and last_lin is not None and last_lin[1] is None and not last_lin[2] \
+                    and last_lin[0].bias is not None and ops.colsum_supported(D):
+                # the Linear in front of the BatchNorm has no BatchNorm / activation of its own: d IS its pre-activation
+                # gradient, whose column sums (the bias gradient) the apply pass accumulates on the way
+                ws_col = self._fold_ws(last_lin[0], D)
+                pending.append((ws_col, _grad_of(last_lin[0].bias)))
+                folded_last = True
+            Bq = dlog.shape[0]
+            call('sbr_bn_score_bwd_apply', ptr(dlog), ptr(ur), ptr(z), ptr(d), Bq, R // Bq, D, ptr(bn.weight), ptr(mean), ptr(rstd),
+                 ptr(self._bn_ws(bn, D)), ptr(_grad_of(bn.weight)), ptr(_grad_of(bn.bias)), ptr(ws_col), st)
         else:
-            de = a.f32(R, D)
-            call('sbr_aggregate_bwd', ptr(dout), ptr(self.arg), ptr(de), S, k, D, ent._agg_mode, st)
-        if self.reg:
-            dreg = a.f32(R, D)
-            e3, d3 = self.e.view(S, 2, D), dreg.view(S, 2, D)
-            # d(total)/d(reg_loss) = regularization_weight (sgd_alg.py:2002); mean over G*N rows inside the kernel
-            ops.infonce_bwd(e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * D, self.G, self.N, D, self.tau,
-                            self.reg_w / (self.G * self.N), one_f32, d3[:, 0].data_ptr(), d3[:, 1].data_ptr(), 2 * D, dreg.device)
-            de = de.add_(dreg) if k > 1 else dreg.add_(de)
-        d = de
-        if self.tb is not None:
-            x, y, mean, rstd = self.tb
-            d = self._bn_bwd(self.trailing, d, y, x, mean, rstd, 0)
+            if k == 1:
+                de = dout
+            else:
+                de = a.f32(R, D)
+                call('sbr_aggregate_bwd', ptr(dout), ptr(self.arg), ptr(de), S, k, D, ent._agg_mode, st)
+            if self.reg:
+                dreg = a.f32(R, D)
+                e3, d3 = self.e.view(S, 2, D), dreg.view(S, 2, D)
+                # d(total)/d(reg_loss) = regularization_weight (sgd_alg.py:2002); mean over G*N rows inside the kernel
+                ops.infonce_bwd(e3[:, 0].data_ptr(), e3[:, 1].data_ptr(), 2 * D, self.G, self.N, D, self.tau,
+                                self.reg_w / (self.G * self.N), one_f32, d3[:, 0].data_ptr(), d3[:, 1].data_ptr(), 2 * D, dreg.device)
+                de = de.add_(dreg) if k > 1 else dreg.add_(de)
+            d = de
+            if self.tb is not None:
+                x, y, mean, rstd = self.tb
+                d = self._bn_bwd(self.trailing, d, y, x, mean, rstd, 0)
         # gradient of the [R (+1), C] modality matrix: the last producer below writes rows [0, R); the sentinel row is zero
         dx0 = a.f32(R + 1 if self.padded else R, self.C)
         if self.padded:
             dx0[R].zero_()
-        tail = (self.seed is not None) + bool(self.normalize)
+        tail_ops = (self.seed is not None) + bool(self.normalize)
         for li, ((lin, bn, act), (x, z, y, mean, rstd)) in enumerate(zip(reversed(self.layers), reversed(self.acts))):
+            w = lin.weight
+            bias_done = folded_last and li == 0
             if bn is not None:
                 dz = self._bn_bwd(bn, d, y, z, mean, rstd, act)
+            elif act and pending is not None and ops.colsum_supported(d.shape[1]):
+                ws_l = self._fold_ws(lin, d.shape[1])
+                dz = a.f32(d.shape[0], d.shape[1])
+                call('sbr_act_grad_gather_colsum', ptr(d), ptr(y), d.stride(0), None, ptr(dz), dz.stride(0), d.shape[0], d.shape[1],
+                     act, ptr(ws_l), st)
+                pending.append((ws_l, _grad_of(lin.bias)))
+                bias_done = True
             else:
                 dz = ops.act_grad(d, y, act) if act else d
-            w = lin.weight
             ops.matmul_tn(dz, x, out=_grad_of(w))
-            ops.colsum(dz, out=_grad_of(lin.bias))
+            if not bias_done:
+                ops.colsum(dz, out=_grad_of(lin.bias))
             last = li == len(self.layers) - 1
-            d = ops.matmul_nn(dz, w, out=dx0[:R] if (last and not tail) else a.f32(R, w.shape[1]))
+            d = ops.matmul_nn(dz, w, out=dx0[:R] if (last and not tail_ops) else a.f32(R, w.shape[1]))
         if self.seed is not None:
-            tail -= 1
-            dd = dx0[:R] if not tail else a.f32(R, self.C)
+            tail_ops -= 1
+            dd = dx0[:R] if not tail_ops else a.f32(R, self.C)
             call('sbr_dropout_dev', ptr(d), ptr(dd), d.numel(), float(self.p_drop), ptr(self.seed[0]), int(self.seed[1]), st)
             d = dd
         if self.normalize:
@@ -279,7 +333,10 @@ class _EntityRun:
         d = dx0
         for (fe, o, n), hs in zip(self.entries, self.hidden):
             ps = fe.front_params()
-            fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps])
+            fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps],
+                              pending=pending)
+        if pending:
+            ops.colred_finish(pending)
 
 
 class _PlainRun:
@@ -400,6 +457,7 @@ class FusedTrainStep:
         self.arena = Arena(dev)
         self.user = (_EntityRun if net.is_user_sb_module else _PlainRun)(net.user_embedding_module, self.arena)
         self.item = _EntityRun(net.item_embedding_module, self.arena)
+        self.item.fuse_tail = os.environ.get('SBR_FUSE_TAIL', '1') != '0'
         self.kind = {RecBinaryCrossEntropy: 0, RecBayesianPersonalizedRankingLoss: 1, RecSampledSoftmaxLoss: 2}[type(rec_loss)]
         self.one64 = torch.ones((), device=dev, dtype=torch.float64)
         self.one32 = torch.ones((), device=dev, dtype=torch.float32)
@@ -468,10 +526,16 @@ class FusedTrainStep:
         B, N = i.shape
         a.reset()
         ur = self.user.forward(u, pu, (seed, 0), su)                 # [B, D]; seed: device int64[1] of this step
-        ir = self.item.forward(i, pi, (seed, 1), si)                 # [B*N, D]
-        D = ir.shape[-1]
+        ir = self.item.forward(i, pi, (seed, 1), si)                 # [B*N, D]; None: the trailing BatchNorm runs inside the scorer
+        tail = self.item.tail if ir is None else None
+        D = self.item.D
         logits = a.f32(B, N)
-        call('sbr_score_dot_fwd', ptr(ur), ptr(ir), ptr(logits), B, N, D, st)
+        if tail is not None:
+            z, mean, rstd = tail
+            bn = self.item.trailing
+            call('sbr_bn_score_fwd', ptr(z), ptr(ur), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), ptr(logits), B, N, D, st)
+        else:
+            call('sbr_score_dot_fwd', ptr(ur), ptr(ir), ptr(logits), B, N, D, st)
         rl = self.rec_loss
         if self.kind == 0:
             scale = 1.0 / (B * N) if rl.aggregator == 'mean' else 1.0
@@ -483,16 +547,26 @@ class FusedTrainStep:
         loss = a.f64()
         dlog = a.f32(B, N)
         call('sbr_rec_loss_fwd_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog), st)
-        dU, dI = a.f32(B, D), a.f32(B * N, D)
-        call('sbr_score_dot_bwd', ptr(dlog), ptr(ur), ptr(ir), ptr(dU), ptr(dI), B, N, D, st)
+        dU = a.f32(B, D)
+        if tail is not None:
+            # dU and the BatchNorm column sums in one pass over the pre-BatchNorm rows; the item gradient dlog[s] * u[b] is
+            # recomputed by the apply pass of phase 2 instead of being stored
+            z, mean, rstd = tail
+            bn = self.item.trailing
+            call('sbr_bn_score_bwd_stats', ptr(dlog), ptr(ur), ptr(z), ptr(dU), B, N, D, ptr(bn.weight), ptr(bn.bias), ptr(mean),
+                 ptr(rstd), ptr(self.item._bn_ws(bn, D)), st)
+            dI = None
+        else:
+            dI = a.f32(B * N, D)
+            call('sbr_score_dot_bwd', ptr(dlog), ptr(ur), ptr(ir), ptr(dU), ptr(dI), B, N, D, st)
         self.user.backward(dU, self.one32)
-        self._p2 = (dI, loss)
+        self._p2 = (dI, loss, (dlog, ur) if tail is not None else None)
 
     def _phase2(self):
         """The item side's backward (the bulk of the step) and the loss scalars."""
         a, st = self.arena, ops.stream()
-        dI, loss = self._p2
-        self.item.backward(dI, self.one32)
+        dI, loss, tail = self._p2
+        self.item.backward(dI, self.one32, tail)
         out = a.f64(3)                                               # (total, rec, reg)
         ru, ri = self.user.reg_loss, self.item.reg_loss
         call('sbr_pack_losses', ptr(loss), ptr(ru), float(getattr(self.user, 'reg_w', 0.0)), ptr(ri),

@@ -172,6 +172,38 @@ def act_grad(dy, y, act: int, idx=None, n_rows=None):
     return dz
 
 
+def colsum_supported(C: int) -> bool:
+    """Column sums folded into the producer of their input (sbr_act_grad_gather_colsum, sbr_bn_score_bwd_apply)."""
+    return bool(lib().sbr_act_grad_colsum_supported(int(C)))
+
+
+def new_colsum_ws(device, C: int) -> torch.Tensor:
+    """Zeroed column-reduction workspace (totals + replicas) of one pending reduction; its finishing kernel re-zeroes it."""
+    return torch.zeros(COLRED_WS_FACTOR * C, device=device, dtype=torch.float64)
+
+
+def act_grad_colsum(dy, y, act: int, ws, idx=None, n_rows=None):
+    """act_grad that also leaves the column sums of its result pending in ``ws`` (complete them with ``colred_finish``)."""
+    n = n_rows if n_rows is not None else (idx.numel() if idx is not None else dy.shape[0])
+    C = dy.shape[1]
+    dz = torch.empty(n, C, device=dy.device, dtype=torch.float32)
+    call('sbr_act_grad_gather_colsum', ptr(dy), ptr(y), dy.stride(0), ptr(idx), ptr(dz), C, n, C, act, ptr(ws), stream())
+    return dz
+
+
+def colred_finish(pending) -> None:
+    """pending: [(workspace, out float vector [C])] of folded column sums -> one launch per 8 of them."""
+    import ctypes
+    for lo in range(0, len(pending), 8):
+        part = pending[lo:lo + 8]
+        n = len(part)
+        wsa = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in part])
+        outa = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in part])
+        ca = (ctypes.c_int * n)(*[o.numel() for _, o in part])
+        call('sbr_colred_finish', n, ctypes.cast(wsa, ctypes.c_void_p), ctypes.cast(outa, ctypes.c_void_p),
+             ctypes.cast(ca, ctypes.c_void_p), stream())
+
+
 # ---- Linear (+ activation) ----------------------------------------------------------------------------------------------
 class LinearActFn(Function):
     """y = act(x @ W^T + b) — nn.Linear + activation of modules/polylinear.py:51,63-72."""

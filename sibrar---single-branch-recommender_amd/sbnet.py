@@ -236,6 +236,7 @@ class FeatureEmbedding(nn.Module):
             w = lin.weight.data
             lin.weight = nn.Parameter(w.t().contiguous().t())
         self._act = ops.act_code(activation_fn)
+        self._colsum_ws = {}            # layer -> column-reduction workspace of its folded bias gradient (fused step)
 
     # -- front-end protocol used by FrontEndFn ---------------------------------------------------------------------------
     @property
@@ -297,9 +298,12 @@ class FeatureEmbedding(nn.Module):
             h = dst
         return hidden
 
-    def front_backward(self, p, hidden, rows, n, out, dout, slots, grad_out=None):
+    def front_backward(self, p, hidden, rows, n, out, dout, slots, grad_out=None, pending=None):
         """Gradients of this modality's parameters. ``grad_out`` (optional): tensors to write into instead of fresh ones —
-        lookup-table gradients are ACCUMULATED into them (they must be zero-initialised), dense ones are overwritten."""
+        lookup-table gradients are ACCUMULATED into them (they must be zero-initialised), dense ones are overwritten.
+        ``pending`` (optional list, needs ``grad_out``): the bias gradients are left pending as column sums folded into the
+        activation-derivative kernels — (workspace, bias gradient) pairs are appended and the caller completes them with
+        ``ops.colred_finish`` (one launch for all layers of a step instead of two per bias)."""
         t = self._table
         st = stream()
         if self.kind == 'categorical':
@@ -315,10 +319,25 @@ class FeatureEmbedding(nn.Module):
         L = len(p) // 2
         grads = [None] * (2 * L)
         go = grad_out if grad_out is not None else [None] * (2 * L)
-        dz = ops.act_grad(dout, out, self._act, idx=slots, n_rows=n)           # [n, C] compact
+
+        def dz_of(dy, y, l, idx=None, n_rows=None):
+            """dy * act'(y) (rows gathered through idx) and the bias gradient of layer l: folded or by its own reduction"""
+            C = dy.shape[1]
+            if pending is not None and go[2 * l + 1] is not None and ops.colsum_supported(C) and dy.stride(0) % 4 == 0:
+                ws = self._colsum_ws.get(l)
+                if ws is None:
+                    ws = self._colsum_ws[l] = ops.new_colsum_ws(dy.device, C)
+                dz_ = ops.act_grad_colsum(dy, y, self._act, ws, idx=idx, n_rows=n_rows)
+                pending.append((ws, go[2 * l + 1]))
+                grads[2 * l + 1] = go[2 * l + 1]
+                return dz_
+            dz_ = ops.act_grad(dy, y, self._act, idx=idx, n_rows=n_rows)
+            grads[2 * l + 1] = ops.colsum(dz_, out=go[2 * l + 1])
+            return dz_
+
+        dz = dz_of(dout, out, L - 1, idx=slots, n_rows=n)                     # [n, C] compact
         for l in range(L - 1, -1, -1):
             W = p[2 * l]
-            grads[2 * l + 1] = ops.colsum(dz, out=go[2 * l + 1])
             if l == 0 and self.kind == 'csr':
                 # the projector weight is column-major: its gradient is accumulated in the same [n_cols, C] layout
                 if go[0] is not None:
@@ -334,7 +353,7 @@ class FeatureEmbedding(nn.Module):
             else:
                 grads[2 * l] = ops.matmul_tn(dz, hidden[l - 1], n_rows=n, out=go[2 * l])
                 dh = ops.matmul_nn(dz, W if W.stride(1) == 1 else W.contiguous())
-                dz = ops.act_grad(dh, hidden[l - 1], self._act)
+                dz = dz_of(dh, hidden[l - 1], l - 1)
         return grads
 
     # -- stand-alone use (plain user / item side of SingleBranchNet) -------------------------------------------------------
