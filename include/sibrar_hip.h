@@ -300,6 +300,34 @@ long sbr_score_topk_f16_workspace(long Bu, int I, int k);
 /* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
 int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);
 
+/* ---- native batch producer (csrc/producer.hip) --------------------------------------------------------------------------------
+ * One C++ thread runs the host side of the training step ahead of the launch thread: the default collate of the reference
+ * (data/dataloader.py:154-198: bit-exact draws from numpy's legacy MT19937 stream, `v in positives` on the resident interaction
+ * CSR), the modality draw of every index slot (algorithms/sgd_alg.py:1904-1927, utilities/utils.py:60-90: PCG64 + numpy's Lemire
+ * draws), the per-modality launch plan, and ONE packed host-to-device copy per batch into a ring of caller-allocated device
+ * slots: [users | users[0] | items | items[0] | user draw | item draw | dropout seed], 16-byte aligned segments.
+ * Generator states are handed in by sbr_producer_start and back by sbr_producer_stop. Exception to the "no ownership" rule:
+ * the handle owns its pinned staging buffers, query scratch, stream and events. Batches must be consumed in order, one at a
+ * time: sbr_producer_next -> sbr_producer_wait(stream) -> launches that read the slot -> sbr_producer_release(stream).
+ * descriptor (32 longs): 0 slot, 1 B, 2 packed bytes, 3..8 segment offsets (users, items, user draw, item draw, seed, end),
+ * 9 / 10 rows of the user / item draw, 11..18 user counts per modality (padded to the graph's bucket grid when pad != 0),
+ * 19..26 item counts, 27 batch number. */
+void* sbr_producer_create(int device, long B, int n_neg, long n_cand, const long* items_in_split, const long* h_indptr,
+                          const int* h_indices, const long* d_indptr, const int* d_indices, long host_below, int pad, int n_slots,
+                          long slot_bytes, void* const* slot_dev);
+int sbr_producer_set_entity(void* handle, int which, int enabled, int n_mod, int k, int central);
+int sbr_producer_start(void* handle, const long* rows_e, const long* cols_e, long n_inter, long first, long stride, long n_batches,
+                       const unsigned int* mt_key, int mt_pos, const unsigned long long* pcg, long seed_base, long n_prepared);
+int sbr_producer_next(void* handle, long* desc);
+int sbr_producer_wait(void* handle, int slot, void* stream);
+int sbr_producer_release(void* handle, int slot, void* stream);
+int sbr_producer_stop(void* handle, unsigned int* mt_key, int* mt_pos, unsigned long long* pcg, long* out_counters);
+int sbr_producer_destroy(void* handle);
+/* the producer's generator replica and plan padding on their own (host only; pinned against numpy / the Python formulation by
+ * tests/test_host_cpu.py). pcg: (state hi, state lo, inc hi, inc lo, has_uint32, uinteger) of numpy's PCG64, updated in place. */
+int sbr_host_pcg64_modalities(unsigned long long* pcg, long n_slots, int n_mod, int k, int central, signed char* out, long* counts);
+int sbr_host_pad_counts(long* counts, int n_mod, long R);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ class SibrarHipError(RuntimeError):
 
 _CTYPES = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
-    'unsigned long long': ctypes.c_ulonglong,
+    'unsigned long long': ctypes.c_ulonglong, 'unsigned int': ctypes.c_uint, 'signed char': ctypes.c_byte,
 }
 
 
@@ -34,7 +34,8 @@ def parse_header(path: str = HEADER_PATH):
     for m in re.finditer(r'([A-Za-z_][\w\s\*]*?)\b(sbr_\w+)\s*\(([^;{}]*?)\)\s*;', text, flags=re.S):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
         ret = ret.replace('extern "C"', '').strip()
-        restype = ctypes.c_char_p if '*' in ret else _CTYPES.get(ret.replace('const', '').strip(), ctypes.c_int)
+        restype = (ctypes.c_char_p if 'char' in ret else ctypes.c_void_p) if '*' in ret \
+            else _CTYPES.get(ret.replace('const', '').strip(), ctypes.c_int)
         argtypes, argnames = [], []
         if args and args != 'void':
             for a in args.split(','):

@@ -153,6 +153,7 @@ class NegativeSamplingDataLoader:
         self._prepare_takes_key = None
         self._identity_items = is_arange(np.asarray(dataset.items_in_split))
         self._pos_rows, self._pop = None, None
+        self._native = None          # native_loader.NativeBatchProducer, created on first use
 
     def __len__(self):
         if self.dp_sampling == 'local' and self.world > 1:
@@ -161,7 +162,44 @@ class NegativeSamplingDataLoader:
             n = (len(self.rows) + self.batch_size - 1) // self.batch_size
         return n if self.max_batches is None else min(n, self.max_batches)
 
+    def _native_producer(self):
+        """The native batch producer (native_loader.py / csrc/producer.hip) when ``prepare_fn`` is a FusedTrainStep's ``prepare``
+        and the loader runs its default path; None otherwise (the Python pipeline below serves every other configuration)."""
+        fused = getattr(self.prepare_fn, '__self__', None)
+        if fused is None or type(fused).__name__ != 'FusedTrainStep' or self.draw_fn is not None:
+            return None
+        from . import native_loader
+        if not native_loader.eligible(self, fused):
+            return None
+        if self._native is None or self._native.fused is not fused or self._native.B != self.batch_size:
+            if self._native is not None:
+                self._native.close()
+            self._native = native_loader.NativeBatchProducer(self, fused)
+        return self._native
+
+    def _native_iter(self, prod):
+        n = len(self.rows)
+        order = loader_epoch_order(n) if self.shuffle else np.arange(n)
+        rows_e, cols_e = (self.rows[order], self.cols[order]) if self.shuffle else (self.rows, self.cols)
+        local = self.dp_sampling == 'local' and self.world > 1
+        first, stride = (self.rank * self.batch_size, self.world * self.batch_size) if local else (0, self.batch_size)
+        prod.start(rows_e, cols_e, first, stride, len(self))
+        _LIVE_LOADERS.add(self)
+        try:
+            while True:
+                pb = prod.next_batch()
+                if pb is None:
+                    break
+                yield None, None, None, pb
+        finally:
+            prod.stop()
+
     def __iter__(self):
+        if self.prefetch > 0 and self.prepare_fn is not None:
+            prod = self._native_producer()
+            if prod is not None:
+                self.close()
+                return self._native_iter(prod)
         if self.prefetch <= 0:
             return self._produce()
         import queue
@@ -240,6 +278,8 @@ class NegativeSamplingDataLoader:
     def close(self):
         """Stop the producer threads of the current iteration (also run at interpreter exit: a thread that is inside a
         HIP call while Python finalises aborts the process)."""
+        if getattr(self, '_native', None) is not None:
+            self._native.stop()
         live = getattr(self, '_live', None)
         if live is None:
             return

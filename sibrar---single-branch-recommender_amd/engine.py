@@ -591,6 +591,7 @@ class FusedTrainStep:
         pb.u_shape, pb.i_shape = tuple(u.shape), tuple(i.shape)
         pb.pu, pb.pi = self.user.plan(du, pad), self.item.plan(di, pad)
         pb.packed = pb.layout = None
+        pb.native = None             # (NativeBatchProducer, slot) for batches of the native producer (native_loader.py)
         self._n_prepared += 1                                        # dropout seed of this step (travels with the batch)
         seed = (torch.initial_seed() * 1000003 + 2 * self._n_prepared) & 0x3FFFFFFFFFFFFFFF
         pb.lab_cached = False
@@ -700,6 +701,9 @@ class FusedTrainStep:
             raise RuntimeError('FusedTrainStep.step() needs the model in train mode')
         with pin_stream():
             pb = draws if isinstance(draws, PreparedBatch) else self.prepare(u_idxs, i_idxs, labels, draws, ahead=False)
+            native = getattr(pb, 'native', None)
+            if native is not None:
+                native[0].wait(native[1])                            # this stream waits for the producer's upload of the slot
             if pb.event is not None:
                 cur = torch.cuda.current_stream()
                 cur.wait_event(pb.event)
@@ -756,6 +760,8 @@ class FusedTrainStep:
                 d.update(self._touched_rows if self._sparse else pb.u[:-1])   # also re-zeroes the gradient rows it consumed
                 g[:d.lo].zero_()
                 g[d.hi:].zero_()
+            if native is not None:
+                native[0].release(native[1])                         # everything queued so far has read the slot
             return out
 
     def flush(self):
@@ -861,7 +867,7 @@ class FusedTrainStep:
 
 class PreparedBatch:
     """Device-resident inputs of one step + its launch plan (``FusedTrainStep.prepare``)."""
-    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'seed', 'pu', 'pi', 'u_shape', 'i_shape', 'event', 'lab_cached')
+    __slots__ = ('packed', 'layout', 'u', 'i', 'lab', 'su', 'si', 'seed', 'pu', 'pi', 'u_shape', 'i_shape', 'event', 'lab_cached', 'native')
 
 
 _LIVE = weakref.WeakSet()

@@ -71,6 +71,14 @@ class Trainer:
                 train_loader.prepare_fn = self.fused.prepare
                 if train_loader.prefetch <= 0:
                     train_loader.prefetch = 4
+        # an epoch that stops after `max_batches_per_epoch` (trainer.py:225-227) must not leave a producer running ahead on the
+        # random streams: the loader is told the cap (its producers then stop exactly there) while the loss averages keep the
+        # reference's denominator, the uncapped number of batches (trainer.py:233)
+        self._n_batches_uncapped = None
+        if train_loader is not None and self.max_batches is not None and hasattr(train_loader, 'max_batches'):
+            self._n_batches_uncapped = len(train_loader)
+            if train_loader.max_batches is None or train_loader.max_batches > self.max_batches:
+                train_loader.max_batches = self.max_batches
         logging.info(f'Built Trainer module - optimizer: {self.optimizer.name} lr: {self.lr} wd: {self.wd}')
 
     def fit(self):
@@ -132,7 +140,7 @@ class Trainer:
     def _train(self):
         self.model.train()
         sums = {}
-        n_batches = len(self.train_loader)
+        n_batches = self._n_batches_uncapped if self._n_batches_uncapped is not None else len(self.train_loader)
         for batch_count, batch in enumerate(self.train_loader):
             total, rec, regs = self.train_step(*batch)
             vals = {'loss': total, 'rec_loss': rec, **regs}
@@ -141,6 +149,8 @@ class Trainer:
                 sums[k] = v if k not in sums else sums[k] + v
             if self.max_batches is not None and self.max_batches <= batch_count + 1:
                 print(f'limit of {self.max_batches} batches hit, thus stopping this training cycle.')
+                if hasattr(self.train_loader, 'close'):
+                    self.train_loader.close()                                    # stop producers before anything else draws
                 break
         if hasattr(self.pointer_to_model, 'check_index_errors'):
             self.pointer_to_model.check_index_errors()                               # ids without a feature row -> KeyError

@@ -472,8 +472,8 @@ def test_c4_step_on_one_gpu_at_full_table_shapes():
                                             1, lr, wd)
         if k_ == 'user_embedding_module.embedding_layer.weight':
             close(p.detach()[rows].cpu(), want[rows].cpu(), what=f'{k_} (touched + sampled rows)', rtol=1e-5, atol=1e-7)
-            assert abs(float(p.detach().double().sum() - want.sum())) <= 1e-7 * float(want.abs().sum())
-            assert abs(float(p.detach().double().pow(2).sum() - want.pow(2).sum())) <= 1e-7 * float(want.pow(2).sum())
+            assert abs(float(p.detach().double().sum() - want.sum())) <= 1e-6 * float(want.abs().sum())
+            assert abs(float(p.detach().double().pow(2).sum() - want.pow(2).sum())) <= 1e-6 * float(want.pow(2).sum())
         else:
             # elements whose gradient is rounding noise around zero take +-lr steps of either sign under Adam (golden_util.
             # bn_shadowed_biases): the replay's gradient bits equal pass 1's only up to summation order, so compare where

@@ -400,3 +400,63 @@ def test_full_evaluator_config_validation():
     with pytest.raises(ValueError, match='not supported'):
         S.FullEvaluator(ev._Cfg(metrics=['ndcg', 'auc']))
     assert list(feats['gender'].get_labels([1, 0])) == ['M', 'F']
+
+
+def _pcg_state_words(rng):
+    st = rng.bit_generator.state
+    s, inc = int(st['state']['state']), int(st['state']['inc'])
+    m = (1 << 64) - 1
+    return [s >> 64, s & m, inc >> 64, inc & m, int(st['has_uint32']), int(st['uinteger'])]
+
+
+def test_native_pcg64_modality_draw_equals_numpy_generator():
+    """csrc/producer.hip's PCG64 + Lemire replica against numpy's Generator through the product's Python formulation
+    (sampling.sample_modalities, itself pinned by the G7 golden streams): k = 1, k = 2 and central-modality draws for 1..6
+    modalities, from fresh generators and from states with a buffered 32-bit half; positions, per-modality counts and the
+    generator state afterwards must be identical (checked by drawing once more from both)."""
+    import ctypes
+    import sibrar_amd as S
+    from importlib import import_module
+    _lib = import_module('sibrar---single-branch-recommender_amd._lib')
+    lib = _lib.lib()
+    for seed in (42, 7):
+        for n_mod in (1, 2, 3, 4, 6):
+            for reg, k, central in (('no_regularization', 1, None), ('pairwise_single', 2, None), ('central_modality', 2, 1)):
+                if k > n_mod or (central is not None and n_mod < 2):
+                    continue
+                order = [f'm{i}' for i in range(n_mod)]
+                for warm in (0, 1, 3):                      # odd numbers of 32-bit draws leave a buffered half behind
+                    ref = np.random.default_rng(seed)
+                    for _ in range(warm):
+                        ref.integers(0, 5)
+                    words = (ctypes.c_ulonglong * 6)(*_pcg_state_words(ref))
+                    n_slots = 2816
+                    want = S.sampling.sample_modalities(ref, order, n_slots, reg, order[central] if central is not None else None)
+                    got = np.empty((n_slots, k), dtype=np.int8)
+                    counts = (ctypes.c_long * 8)()
+                    rc = lib.sbr_host_pcg64_modalities(ctypes.cast(words, ctypes.c_void_p), n_slots, n_mod, k,
+                                                       -1 if central is None else central, got.ctypes.data,
+                                                       ctypes.cast(counts, ctypes.c_void_p))
+                    assert rc == 0, lib.sbr_last_error()
+                    assert np.array_equal(got, want), (seed, n_mod, reg, warm)
+                    assert list(counts)[:n_mod] == np.bincount(want.reshape(-1), minlength=n_mod).tolist()
+                    assert list(words) == _pcg_state_words(ref), 'generator state after the draw'
+
+
+def test_native_plan_padding_equals_engine_plan():
+    """sbr_host_pad_counts == the bucket arithmetic of engine._EntityRun.plan (graph-mode capacities of the slot lists)."""
+    import ctypes
+    import math
+    from importlib import import_module
+    lib = import_module('sibrar---single-branch-recommender_amd._lib').lib()
+    rng = np.random.default_rng(0)
+    for R in (6, 64, 2816, 5632, 90112, 180224, 999, 123457):
+        for n_mod in (1, 2, 3, 5):
+            raw = rng.multinomial(R, np.ones(n_mod) / n_mod)
+            raw[rng.integers(0, n_mod)] = 0 if n_mod > 1 else raw[0]
+            bucket = max(64, -(-int(5.0 * math.sqrt(R)) // 64) * 64)
+            off = (R // n_mod + bucket // 2) % bucket
+            want = np.where(raw > 0, (np.maximum(raw - off, 0) + bucket - 1) // bucket * bucket + off, 0)
+            got = (ctypes.c_long * n_mod)(*[int(c) for c in raw])
+            assert lib.sbr_host_pad_counts(ctypes.cast(got, ctypes.c_void_p), n_mod, R) == 0
+            assert list(got) == want.tolist(), (R, n_mod)
