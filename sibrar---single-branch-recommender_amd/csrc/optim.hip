@@ -7,17 +7,25 @@
 // One element of one Adam / AdamW step. The dense kernel and the row-wise (deferred) kernels below go through this one inlined
 // function with run-time operands, so that a deferred row replays exactly the instruction sequence the dense kernel would have
 // executed for it (same contractions, same rounding).
-struct AdamHyper { float lr, b1, b2, eps, wd; int decoupled; };
+// omb1 / omb2 / decay: 1 - beta1, 1 - beta2, 1 - lr * wd evaluated in DOUBLE on the host and rounded to fp32 once, as torch does
+// with its Python-float scalars (1 - 0.999 -> 0.001f; evaluated in fp32 it is 0.99998713e-3: a 6e-6 relative bias of every Adam
+// step, found by the 257 M-parameter c4 test against the fp64 update rule)
+struct AdamHyper { float lr, b1, b2, eps, wd; int decoupled; float omb1, omb2, decay; };
+static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int decoupled) {
+  AdamHyper h = {(float)lr, (float)b1, (float)b2, (float)eps, (float)wd, decoupled, (float)(1.0 - b1), (float)(1.0 - b2),
+                 (float)(1.0 - lr * wd)};
+  return h;
+}
 
 __device__ __forceinline__ void adam_element(float& pe, float ge, float& me, float& ve, const AdamHyper& h, float step_size,
                                              float bc2_sqrt) {
   // no fused multiply-add contraction here: left to itself the compiler contracts differently in different callers (mul + add
   // in the dense kernel, v_pk_fma in the flush kernel), and a deferred row must round exactly like a densely updated one
 #pragma clang fp contract(off)
-  if (h.decoupled) pe *= (1.f - h.lr * h.wd);     // AdamW: p.mul_(1 - lr * wd)
+  if (h.decoupled) pe *= h.decay;                 // AdamW: p.mul_(1 - lr * wd)
   else ge += h.wd * pe;                            // Adam: grad = grad.add(p, alpha=wd)
-  me = me + (ge - me) * (1.f - h.b1);              // exp_avg.lerp_(grad, 1 - beta1)
-  ve = ve * h.b2 + (1.f - h.b2) * ge * ge;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  me = me + (ge - me) * h.omb1;                    // exp_avg.lerp_(grad, 1 - beta1)
+  ve = ve * h.b2 + h.omb2 * ge * ge;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
   const float denom = sqrtf(ve) / bc2_sqrt + h.eps;
   pe = pe - step_size * (me / denom);
 }
@@ -137,7 +145,7 @@ extern "C" int sbr_adam_step(int kind, float* p, const float* g, float* m, float
   if (n == 0) return SBR_OK;
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  const AdamHyper h = {(float)lr, (float)b1, (float)b2, (float)eps, (float)wd, kind == 0};
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
   adamw_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
   SBR_CHECK_LAUNCH("sbr_adam_step");
   return SBR_OK;
@@ -154,7 +162,7 @@ extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, f
   SBR_REQUIRE(mode >= 0 && mode <= 2, "sbr_adam_rows: unknown mode %d", mode);
   SBR_REQUIRE(p && m && v && last && sched, "sbr_adam_rows: null operand");
   SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_rows: step %ld out of range", step);
-  const AdamHyper h = {(float)lr, (float)b1, (float)b2, (float)eps, (float)wd, kind == 0};
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
   float* zero = nullptr;
   if (hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(sbr_adam_zero)) != hipSuccess) {
     sbr_set_error("sbr_adam_rows: hipGetSymbolAddress failed");

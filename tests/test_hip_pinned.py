@@ -561,3 +561,67 @@ def test_group_metrics_on_the_golden_world():
     assert [k for k in res] == [f'ndcg@{k}' for k in (1, 2, 3, 4, 5, 6, 10, 15, 20)]
     for k in (1, 10, 20):
         assert abs(res[f'ndcg@{k}'] - float(z[f'ndcg@{k}'].mean())) < 1e-6
+
+
+# ---- f) the native batch producer (csrc/producer.hip) against the Python formulation of the same host work -----------------------------
+@pytest.mark.parametrize('world,user_entity,reg', [(1, False, 'no_regularization'), (1, True, 'pairwise_single'),
+                                                   (2, False, 'central_modality')])
+def test_native_producer_batches_equal_the_python_pipeline(world, user_entity, reg, monkeypatch):
+    """Every batch the C++ producer thread uploads — users, items with their negatives (MT19937 stream, membership rounds on the
+    GPU kernel and on the host copy), the modality draws of both sides (PCG64 replica), the dropout seed, the padded per-modality
+    counts of the launch plan — equals what the Python pipeline (sampling.recbole_negative_collate + FusedTrainStep.prepare, pinned
+    by the golden streams G6 / G7) produces from the same generator states; including the ragged last batch of the epoch, a
+    second epoch, and the states of numpy's global generator, of the entities' generators and of the seed counter afterwards.
+    world = 2: rank-local sampling (rank 1's slices)."""
+    ds = S().SyntheticDataset(700, 300, 5000, item_dense={'text': 24}, item_tags={'genres': (9, 3)}, user_categorical={'gender': 3},
+                              seed=4, n_negative_samples=5)
+    item = {'features': [{'feature_name': 'text'}, {'feature_name': 'genres'}, {'feature_name': 'item_embedding'}],
+            'single_branch_hidden_layers': [16], 'preference_hidden_layers': [], 'common_modality_dim': 16,
+            'embedding_regularization_type': reg, 'regularization_weight': 0.1}
+    if reg == 'central_modality':
+        item['central_modality'] = 'genres'
+    user = ({'features': [{'feature_name': 'interactions'}, {'feature_name': 'gender'}], 'single_branch_hidden_layers': [],
+             'preference_hidden_layers': [], 'common_modality_dim': 16, 'embedding_regularization_type': 'pairwise_single',
+             'regularization_weight': 0.02} if user_entity else {'feature_name': 'user_embedding', 'embedding_dim': -1})
+    cfg = {'shared_common_dim': 16, 'user': user, 'item': item}
+    B = 512
+    runs = {}
+    for native in ('0', '1'):
+        monkeypatch.setenv('SBR_NATIVE_PRODUCER', native)
+        torch.manual_seed(21)
+        np.random.seed(21)
+        net = S().SingleBranchNet(S().SingleBranchNetConfig.from_dict(cfg), ds).to(DEV).train()
+        lossf = S().RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=5)
+        fused = S().FusedTrainStep(net, lossf, S().FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=0.))
+        loader = S().NegativeSamplingDataLoader(ds, batch_size=B, shuffle=True, device=DEV, prefetch=3, prepare_fn=fused.prepare,
+                                                rank=world - 1, world=world, dp_sampling='local')
+        loader.positives.HOST_BELOW = 600            # first rounds (2,560 pairs) on the GPU kernel, redraw rounds on the host
+        got = []
+        for _ in range(2):                               # two epochs: the states handed back feed the next epoch
+            for batch in loader:
+                pb = batch[3]
+                if pb.native is not None:
+                    pb.native[0].wait(pb.native[1])
+                elif pb.event is not None:
+                    torch.cuda.current_stream().wait_event(pb.event)
+                torch.cuda.synchronize()
+                got.append(dict(u=pb.u.cpu().numpy().copy(), i=pb.i.cpu().numpy().copy(), si=pb.si.cpu().numpy().copy(),
+                                su=None if pb.su is None else pb.su.cpu().numpy().copy(), seed=int(pb.seed.cpu()[0]),
+                                pu=None if pb.pu is None else pb.pu[1:], pi=pb.pi[1:], shapes=(pb.u_shape, pb.i_shape)))
+                if pb.native is not None:
+                    pb.native[0].release(pb.native[1])
+        assert (loader._native is not None) == (native == '1')
+        loader.close()
+        ents = ([net.user_embedding_module] if user_entity else []) + [net.item_embedding_module]
+        runs[native] = (got, np.random.randint(0, 1 << 30), [int(e._rng.integers(0, 1 << 30)) for e in ents], fused._n_prepared)
+    py, nat = runs['0'], runs['1']
+    n_per_epoch = len(ds) // (B * world) if world > 1 else -(-len(ds) // B)
+    assert len(py[0]) == len(nat[0]) == 2 * n_per_epoch
+    if world == 1:
+        assert py[0][n_per_epoch - 1]['shapes'][0][0] == len(ds) % B          # the ragged last batch of the epoch
+    for b, (a, c) in enumerate(zip(py[0], nat[0])):
+        assert a['shapes'] == c['shapes'] and a['pi'] == c['pi'] and a['pu'] == c['pu'], (b, a['pi'], c['pi'])
+        assert a['seed'] == c['seed']
+        for k_ in ('u', 'i', 'si', 'su'):
+            assert (a[k_] is None and c[k_] is None) or np.array_equal(a[k_], c[k_]), (b, k_)
+    assert py[1:] == nat[1:], 'generator states / seed counter after two epochs'
