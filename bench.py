@@ -82,10 +82,11 @@ def run_steps(S, trainer, loader_iter, n, world):
     return out
 
 
-def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_kernels):
+def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_kernels, loss=None):
     import torch.distributed as dist
-    loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
-                                   neg_train=ds.n_negative_samples)
+    if loss is None:
+        loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                       neg_train=ds.n_negative_samples)
     trainer = S.Trainer(net, None, None, loss, _Conf(device))
     net.train()
     # three Python threads hand batches to each other (collate -> prepare -> launch). With CPython's default 5 ms switch
@@ -327,6 +328,140 @@ def cpu_baseline(S, ds, net, batch, budget_s=20.0):
                       f'torch {torch.__version__} CPU fp32, {cores} threads)', 'step_seconds': step_s}
 
 
+# ---- BASELINE configs[0] ("c1"): the reference's own CPU-runnable case, GPU engine and CPU port side by side ----------------------
+C1 = dict(n_users=5816, n_items=3299, nnz=651_034, n_neg=10)
+C1_MODEL = {'shared_common_dim': 64, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+            'item': {'features': [{'feature_name': 'genres'}, {'feature_name': 'text'}],
+                     'single_branch_hidden_layers': [64], 'preference_hidden_layers': [], 'common_modality_dim': 64,
+                     'embedding_regularization_type': 'pairwise_single', 'regularization_temperature': 0.1,
+                     'regularization_weight': 1e-3, 'normalize_single_branch_input': True}}
+
+
+def bench_c1(S, device, steps):
+    """ML-1M-shaped synthetic data (U 5,816, I 3,299, 651k interactions, 18 genre tags + 768-d text, C = D = 64,
+    pairwise InfoNCE, BPR, AdamW) — BASELINE.md section 3: GPU interactions/s at the reference's batch 256 and at 4096, the CPU
+    port (oracle restatement: same torch-CPU ops, same per-row numpy sampling calls as the reference) for >= 50 timed steps of
+    batch 256 on the same inputs and parameters, one full evaluation pass on both (scores/s, NDCG@10), cores stated."""
+    from oracle import eval_ref, losses_ref, model_ref, sampling_ref, train_ref
+    ds = S.SyntheticDataset(C1['n_users'], C1['n_items'], C1['nnz'], item_dense={'text': 768}, item_tags={'genres': (18, 3)}, seed=0,
+                            n_negative_samples=C1['n_neg'], negative_sampling_strategy='uniform_recbole', holdout_per_user=1)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(C1_MODEL), ds).to(device)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    bpr = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                               neg_train=ds.n_negative_samples)
+    out = {'workload': 'BASELINE configs[0] shape: synthetic ML-1M (5,816 users x 3,299 items, 651k interactions, 18 genre tags + '
+                       '768-d text, C = D = 64, hidden [64], pairwise InfoNCE, BPR, 10 negatives, AdamW 1e-3 / 1e-6), user = lookup'}
+    # ---- CPU port first (it must see the initial parameters; the GPU runs train the same net afterwards)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
+    it = {k: model_ref.table_from_feature(f) for k, f in ds.item_features.items()}
+    orders = {'item_train': net.item_embedding_module.train_modality_order, 'item_eval': net.item_embedding_module.eval_modality_order}
+    ref = model_ref.RefSingleBranchNet(sd, C1_MODEL, ut, it, orders=orders)
+    rloss = losses_ref.RefRecLoss('bpr', n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                  neg_train=ds.n_negative_samples)
+    opt = train_ref.make_optimizer('adamw', [p for k, p in sd.items() if p.requires_grad and 'running' not in k], 1e-3, 1e-6)
+    inter = ds.user_sampling_matrix
+    positives = [inter.indices[inter.indptr[u]:inter.indptr[u + 1]] for u in range(ds.n_users)]
+    coo = ds.interaction_matrix
+    rng = np.random.default_rng(0)
+    np.random.seed(42)
+    times = []
+    for s_ in range(5 + 50):
+        sel = rng.integers(0, coo.nnz, size=256)
+        t0 = time.perf_counter()
+        u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
+        train_ref.train_step(ref, rloss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l))
+        times.append(time.perf_counter() - t0)
+    cpu_step = sum(times[5:]) / 50
+    # one CPU evaluation pass on the INITIAL parameters (eval/eval.py:205-222: item representations once, user batches of 256)
+    ev = ds.eval_view()
+    sd_e = {k: v.clone() for k, v in sd0.items()}
+    ref_e = model_ref.RefSingleBranchNet(sd_e, C1_MODEL, ut, it, orders=orders)
+    excl, labels = ev.exclude_data.tocsr(), ev.user_sampling_matrix.tocsr()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        i_repr = ref_e.item_repr(torch.arange(ds.n_items), False)
+        nd = []
+        for lo in range(0, ds.n_users, 256):
+            ub = torch.arange(lo, min(lo + 256, ds.n_users))
+            r = eval_ref.evaluate(ref_e.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray(), labels[lo:lo + 256].toarray(), ks=(10,))
+            nd.append(r['ndcg@10'])
+    cpu_eval = time.perf_counter() - t0
+    cpu_ndcg = float(torch.cat(nd).mean())
+    # ---- the same evaluation pass on the GPU (initial parameters), both scorers
+    gpu_eval = {}
+    for scorer in ('fp32', 'fp16_fused'):
+        for rep in range(2):                                 # second pass: resident CSRs, warm kernels
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            evaluator = S.FullEvaluator(config=S.evaluation._Cfg(top_k=(10,), metrics=['ndcg'], calculate_std=False), dataset=ev)
+            m = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': ev, 'batch_size': 256})(), evaluator, device, scorer=scorer)
+            torch.cuda.synchronize()
+            gpu_eval[scorer] = (time.perf_counter() - t0, m['ndcg@10'])
+    # ---- GPU training throughput
+    gpu = {}
+    for B in (256, 4096):
+        n_steps = max(steps, 50)
+        dt, _ = bench_training(S, ds, net, device, B, n_steps, 5, 0, 1, time_kernels=False, loss=bpr)
+        gpu[f'b{B}'] = {'value': round(B * n_steps / dt, 1), 'unit': 'interactions/s', 'ms_per_step': round(dt / n_steps * 1e3, 3),
+                        'steps': n_steps}
+    n_scores = ds.n_users * ds.n_items
+    out.update({
+        'gpu': gpu,
+        'cpu': {'value': round(256 / cpu_step, 1), 'unit': 'interactions/s', 'ms_per_step': round(cpu_step * 1e3, 2), 'batch': 256,
+                'timed_steps': 50, 'warmup_steps': 5, 'cores': cores, 'kind': 'port',
+                'what': f'oracle restatement of the reference step (torch {torch.__version__} CPU fp32, per-row numpy modality draws, '
+                        f'literal collate loop), same data and initial parameters'},
+        'speedup_vs_cpu': {'b256': round(gpu['b256']['value'] / (256 / cpu_step), 1),
+                           'b4096_vs_cpu_b256': round(gpu['b4096']['value'] / (256 / cpu_step), 1)},
+        'eval': {'scores': n_scores,
+                 'cpu': {'value': round(n_scores / cpu_eval, 1), 'unit': 'scores/s', 'seconds': round(cpu_eval, 3), 'cores': cores,
+                         'ndcg@10': round(cpu_ndcg, 6)},
+                 'gpu_fp32': {'value': round(n_scores / gpu_eval['fp32'][0], 1), 'unit': 'scores/s',
+                              'seconds': round(gpu_eval['fp32'][0], 5), 'ndcg@10': round(gpu_eval['fp32'][1], 6)},
+                 'gpu_fp16_fused': {'value': round(n_scores / gpu_eval['fp16_fused'][0], 1), 'unit': 'scores/s',
+                                    'seconds': round(gpu_eval['fp16_fused'][0], 5), 'ndcg@10': round(gpu_eval['fp16_fused'][1], 6)},
+                 'what': 'one full evaluation pass of the INITIAL parameters: item representations, all users, train exclusions, '
+                         'top-10, NDCG@10 (one held-out item per user)'}})
+    return out
+
+
+def cpu_scoring_sample(S, ds, net, n_users=2048, k=20):
+    """CPU port of the full-catalogue scoring loop of eval/eval.py:205-222 on a bounded sample of the c2 workload: all item
+    representations once, then `n_users` users in batches of 256 (scores, exclusion mask, top-k). -> scores/s on this box's cores."""
+    from oracle import eval_ref, model_ref
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = {k_: v.detach().cpu().clone() for k_, v in net.state_dict().items()}
+    ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
+    it = {'text': model_ref.table_from_feature(ds.item_features['text']),
+          'item_embedding': model_ref.RefTable('categorical', np.arange(ds.n_items), n_categories=ds.n_items)}
+    ref = model_ref.RefSingleBranchNet(sd, model_config(net.config.shared_common_dim), ut, it)
+    excl = ds.user_sampling_matrix_train.tocsr()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        i_repr = ref.item_repr(torch.arange(ds.n_items), False)
+        t_items = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for lo in range(0, n_users, 256):
+            ub = torch.arange(lo, lo + 256)
+            sc = eval_ref.masked_scores(ref.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray())
+            eval_ref.topk(sc, k)
+        t_users = time.perf_counter() - t1
+    # a full pass = item representations once + every user batch at the sampled rate
+    full = t_items + t_users * ds.n_users / n_users
+    return {'value': round(ds.n_users * ds.n_items / full, 1), 'unit': 'scores/s', 'cores': cores, 'kind': 'port',
+            'sample': f'item representations of all {ds.n_items} items ({t_items:.2f} s) + {n_users} of {ds.n_users} users in batches of '
+                      f'256 ({t_users:.2f} s: scores, exclusion mask, top-{k}), extrapolated to the full pass'}
+
+
 def launch_ranks(n: int) -> int:
     """``python bench.py --gpus N`` without an external launcher: start N rank processes of this script (one per GPU, the
     environment torch.distributed.run would give them, rendezvous on 127.0.0.1) BEFORE this process has made any GPU / HIP
@@ -368,6 +503,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scoring', action='store_true')
     ap.add_argument('--no-b256', action='store_true')
+    ap.add_argument('--no-c1', action='store_true')
     ap.add_argument('--small', action='store_true', help='1/10-size workload (debug only; never a reportable number)')
     args = ap.parse_args()
 
@@ -469,6 +605,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(S, ds, net, args.batch_size)
         out['cpu_baseline']['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 1)
+        if 'scoring' in out:
+            out['scoring']['cpu_baseline'] = cpu_scoring_sample(S, ds, net)
+            out['scoring']['cpu_baseline']['speedup_vs_cpu'] = round(out['scoring']['value'] / out['scoring']['cpu_baseline']['value'], 1)
+    if rank == 0 and world == 1 and not args.no_c1 and not args.small:
+        del ds, net
+        out['c1'] = bench_c1(S, device, args.steps)
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():
