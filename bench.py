@@ -175,20 +175,48 @@ PMC_ROWS = {('TN', 128, 768): ('void gemm_ring_kernel<1, true, true, 2>', 196608
             ('NT', 128, 128): ('void gemm_ring_kernel<2, false, false, 2>', 131072)}
 
 
+PMC_SCORER_PREFIX = '_Z23score_topk_f16_t_kernel'        # fused scorer dispatches in the same PMC passes (grid = 224 workgroups x 512)
+
+
+def _pmc_file():
+    """The newest committed PMC summary (profiles/rNN_bench_hbm_traffic.csv, written by tools/profile_round.sh + make_profiles.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench_hbm_traffic.csv')))
+    return files[-1] if files else None
+
+
+def _pmc_rows():
+    import csv
+    path = _pmc_file()
+    if path is None:
+        return None, []
+    return os.path.relpath(path, ROOT), list(csv.reader(l for l in open(path) if not l.startswith('#')))
+
+
 def pmc_traffic(mode, M, N, K, batch):
     """HBM bytes per launch of a GEMM signature from the committed PMC summary (None when the run is not the profiled shape)."""
     if batch != 8192:
-        return None
+        return None, None
     key = {0: ('NT', N, K), 1: ('NN', N, K), 2: ('TN', M, N)}[mode]
     row = PMC_ROWS.get(key)
-    path = os.path.join(ROOT, 'profiles', 'r01_bench_hbm_traffic.csv')
-    if row is None or not os.path.exists(path):
-        return None
-    import csv
-    for r in csv.reader(l for l in open(path) if not l.startswith('#')):
+    path, rows = _pmc_rows()
+    if row is None or path is None:
+        return None, None
+    for r in rows:
         if r[0] == row[0] and r[1] == str(row[1]):
-            return float(r[5]) * 1e6
-    return None
+            return float(r[5]) * 1e6, path
+    return None, None
+
+
+def pmc_scorer_traffic(n_users):
+    """HBM bytes of one fused scoring launch over the c2 catalogue from the same PMC passes (None for another shape)."""
+    path, rows = _pmc_rows()
+    if path is None or n_users != C2['n_users']:
+        return None, None
+    for r in rows:
+        if r[0].startswith(PMC_SCORER_PREFIX) and r[1] == str(-(-n_users // 448) * 512):
+            return float(r[5]) * 1e6, path
+    return None, None
 
 
 def dominant_gemm(timings, steps, batch=None):
@@ -206,11 +234,11 @@ def dominant_gemm(timings, steps, batch=None):
     avg_ms = tot / len(ts)
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    traffic = pmc_traffic(mode, M, N, K, batch)
+    traffic, src = pmc_traffic(mode, M, N, K, batch)
     return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': traffic,
-            'traffic_source': None if traffic is None else 'HBM bytes per launch from profiles/r01_bench_hbm_traffic.csv (rocprofv3 '
-                              '--pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
+            'traffic_source': None if traffic is None else f'HBM bytes per launch from {src} (rocprofv3 --pmc FETCH_SIZE and --pmc '
+                              f'WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
             'kernel': f'fp32 MFMA GEMM (gemm_ring_kernel) mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
                       + (' + split-K slab reduce' if mode == 2 else ''),
             'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps, 4),
@@ -258,7 +286,10 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=3):
             'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
             'sharding': f'items/{world}',
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_MFMA_F16, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_MFMA_F16, 4),
+                         'traffic': pmc_scorer_traffic(ds.n_users)[0] if world == 1 else None,
+                         'traffic_source': pmc_scorer_traffic(ds.n_users)[1] if world == 1 else None,
+                         'algorithmic_bytes': (ds.n_users + (hi - lo)) * int(i16.shape[1]) * 2 + ds.n_users * k * 8,
                          'kernel': 'score_topk_f16_t_kernel',
                          'avg_launch_ms': round(avg_ms, 4)}}
 
