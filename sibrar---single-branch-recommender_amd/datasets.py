@@ -160,6 +160,8 @@ class NegativeSamplingDataLoader:
             n = len(self.rows) // (self.batch_size * self.world)      # whole global steps only: every rank runs the same count
         else:
             n = (len(self.rows) + self.batch_size - 1) // self.batch_size
+            if self.world > 1 and 0 < len(self.rows) % self.batch_size < self.world:
+                n -= 1               # 'global' sampling: a last global batch with fewer rows than ranks is dropped (see _produce)
         return n if self.max_batches is None else min(n, self.max_batches)
 
     def _native_producer(self):
@@ -319,7 +321,14 @@ class NegativeSamplingDataLoader:
                 u, i, l = uniform_negative_collate(bu, bi, self.n_neg, self.dataset.n_items, self.positives)
             # data parallel: every rank consumes the same global streams and keeps its slice (parallel.shard_batch)
             if self.world > 1 and not local:
-                u, i, l = u[self.rank::self.world], i[self.rank::self.world], l[self.rank::self.world]
+                # every rank must hold the SAME number of rows: the step divides each rank's loss by its own row count and
+                # averages the gradients over the ranks, which is the gradient of the global-batch mean only for equal shards —
+                # and a rank without rows would leave the others waiting in the all-reduce. The (at most world - 1) surplus
+                # rows of an incomplete last global batch are dropped on every rank alike.
+                keep = len(u) // self.world * self.world
+                if keep == 0:
+                    continue
+                u, i, l = u[:keep][self.rank::self.world], i[:keep][self.rank::self.world], l[:keep][self.rank::self.world]
             if not prepare:
                 yield torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l)
             elif self.prepare_fn is not None:

@@ -3,7 +3,9 @@
 * training is data parallel over the interaction minibatch: every rank holds a full replica, draws the SAME global batch
   from the same host RNG streams, keeps its slice ``[rank::world]`` and, before the optimizer step, sums the ONE flat fp32
   gradient buffer over RCCL (xGMI) and divides by the world size — the gradient of the mean loss over the global batch.
-  BatchNorm statistics stay rank-local (what DDP does by default; SURVEY.md §7 hard parts).
+  BatchNorm statistics stay rank-local (what DDP does by default; SURVEY.md §7 hard parts). The mean over ranks of the
+  per-rank mean-loss gradients is the gradient of the global-batch mean because the loaders give every rank the same number
+  of rows (an incomplete last global batch loses its surplus rows / is dropped: datasets.NegativeSamplingDataLoader).
 * full-catalogue scoring shards by item: every rank scores all users against its item shard with the fused kernel, the
   per-shard top-k lists ``(score f32, global item idx i32)`` are all-gathered and merged (k-way, exact).
 One process per GPU; ``backend='nccl'`` is RCCL on ROCm, ``gloo`` is used by the CPU tests.

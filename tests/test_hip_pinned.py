@@ -625,3 +625,71 @@ def test_native_producer_batches_equal_the_python_pipeline(world, user_entity, r
         for k_ in ('u', 'i', 'si', 'su'):
             assert (a[k_] is None and c[k_] is None) or np.array_equal(a[k_], c[k_]), (b, k_)
     assert py[1:] == nat[1:], 'generator states / seed counter after two epochs'
+
+
+# ---- g) N-rank numerical parity ("N-GPU vs N x local batch, local BN emulated on CPU") ---------------------------
+@pytest.mark.parametrize('case_name,sparse', [('adamw_lookup', '1'), ('adamw_lookup', '0'), ('adamw_entity', '1')])
+def test_two_rank_data_parallel_parity_with_the_oracle(case_name, sparse, tmp_path):
+    """Two ranks (one process each, sharing this box's GPU, gloo) run three fused data-parallel steps from the golden G8 state:
+    rank r takes rows [r::2] of the reference's recorded batches and modality decisions, BatchNorm statistics stay rank-local,
+    gradients are averaged over the ranks (dense all-reduce, or the all-gather of (row, gradient) pairs for the lookup user table)
+    and every replica takes the same dense optimizer step. The CPU oracle emulates exactly that — each shard through
+    RefSingleBranchNet with its own batch statistics, shard-mean losses, gradients averaged, torch.optim step — and every
+    parameter of BOTH replicas must end where the emulation ends (tolerance of the G8 trajectories); the replicas agree bit for
+    bit; rank 0's running statistics are the emulation's rank-0 statistics."""
+    import subprocess
+    import sys
+    from oracle import losses_ref, model_ref, train_ref
+    from golden_util import ref_tables, side_cfg
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['SBR_SPARSE_EXCHANGE'] = sparse
+    out = str(tmp_path / 'final')
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, 'dp_parity_worker.py'), case_name, str(r), '2', str(tmp_path / 'rdzv'), out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-1500:] for l in logs)
+    got = [np.load(out + f'.rank{r}.npz') for r in range(2)]
+    is_lookup = case_name.endswith('lookup')
+    assert str(got[0]['exchange']) == ('sparse' if (sparse == '1' and is_lookup) else 'dense')
+    # ---- oracle emulation
+    z = load('g8_optim')
+    case = [c for c in MANIFEST['g8_optim']['cases'] if c['name'] == case_name][0]
+    cfg = {'shared_common_dim': case['shared_common_dim'], 'user': side_cfg(case['user']), 'item': side_cfg(case['item'])}
+    orders = {k: case[k2] for k, k2 in [('user_train', 'user_train_order'), ('user_eval', 'user_eval_order'),
+                                        ('item_train', 'item_train_order'), ('item_eval', 'item_eval_order')] if k2 in case}
+    ut, it = ref_tables(world(z))
+    sd = state_dict(z, f'{case_name}/sd0/', requires_grad=True)
+    params = {k: v for k, v in sd.items() if v.requires_grad}
+    opt = train_ref.make_optimizer(case['optimizer'], list(params.values()), case['lr'], case['wd'])
+    stats = [{k: v.clone() for k, v in sd.items() if not v.requires_grad} for _ in range(2)]       # rank-local BatchNorm buffers
+    for s in range(3):
+        grads = {k: torch.zeros_like(v) for k, v in params.items()}
+        for r in range(2):
+            sd_r = dict(params)
+            sd_r.update(stats[r])
+            ref = model_ref.RefSingleBranchNet(sd_r, cfg, ut, it, orders=orders)
+            u, i, labels = (torch.from_numpy(z[f'{case_name}/{k}{s}'])[r::2] for k in ('u', 'i', 'labels'))
+            key = f'{case_name}/user_mods{s}'
+            um = z[key][r::2] if key in z.files else None
+            logits = ref.forward(u, i, True, um, z[f'{case_name}/item_mods{s}'][r::2])
+            loss = losses_ref.bpr_loss(logits, labels) + ref.get_and_reset_other_loss()['reg_loss'].sum()
+            for p in params.values():
+                p.grad = None
+            loss.backward()
+            for k, p in params.items():
+                if p.grad is not None:
+                    grads[k] += p.grad / 2
+            close(got[r]['losses'][s], float(losses_ref.bpr_loss(logits, labels)), what=f'rank {r} loss {s}', rtol=2e-4, atol=1e-5)
+        for k, p in params.items():
+            p.grad = grads[k]
+        opt.step()
+    skip = bn_shadowed_biases(sd.keys())
+    for k, v in params.items():
+        assert np.array_equal(got[0][k], got[1][k]), f'replicas differ in {k}'
+        if k not in skip:
+            close(got[0][k], v.detach(), what=k, rtol=2e-4, atol=2e-5, norm_rtol=1e-4)
+    for r in range(2):
+        for k, v in stats[r].items():
+            if k not in skip:
+                close(got[r][k], v, what=f'rank {r} {k}', rtol=2e-4, atol=2e-5, norm_rtol=1e-4)
