@@ -34,7 +34,13 @@ def main():
         lut = {m: i for i, m in enumerate(order)}
         return np.vectorize(lut.__getitem__, otypes=[np.int8])(np.asarray(names)).reshape(-1, names.shape[-1]), order
 
-    losses = []
+    losses, seen = [], []
+    real_step = opt.step_flat
+
+    def recording_step(*a, **k):                      # the averaged gradients every replica is about to apply
+        seen.append({name: p.grad.detach().cpu().numpy().copy() for name, p in net.named_parameters()})
+        return real_step(*a, **k)
+    opt.step_flat = recording_step
     for s in range(3):
         u, i, labels = (torch.from_numpy(z[f'{case_name}/{k}{s}'])[rank::world].contiguous() for k in ('u', 'i', 'labels'))
         key = f'{case_name}/user_mods{s}'
@@ -45,7 +51,8 @@ def main():
     torch.cuda.synchronize()
     exchange = 'sparse' if fused._sparse else 'dense'
     fused.close()
-    np.savez(out_path + f'.rank{rank}.npz', losses=np.array(losses), exchange=np.array(exchange),
+    grads = {f'g{s}/{k}': v for s, d in enumerate(seen) for k, v in d.items()}
+    np.savez(out_path + f'.rank{rank}.npz', losses=np.array(losses), exchange=np.array(exchange), **grads,
              **{k: v.detach().cpu().numpy() for k, v in net.state_dict().items()})
     dist.barrier()
     dist.destroy_process_group()

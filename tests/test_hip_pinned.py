@@ -680,15 +680,24 @@ def test_two_rank_data_parallel_parity_with_the_oracle(case_name, sparse, tmp_pa
             for k, p in params.items():
                 if p.grad is not None:
                     grads[k] += p.grad / 2
-            close(got[r]['losses'][s], float(losses_ref.bpr_loss(logits, labels)), what=f'rank {r} loss {s}', rtol=2e-4, atol=1e-5)
+            close(got[r]['losses'][s], float(losses_ref.bpr_loss(logits, labels).detach()), what=f'rank {r} loss {s}', rtol=2e-4, atol=1e-5)
+        sc = gscale(grads.values())
         for k, p in params.items():
             p.grad = grads[k]
+            # the averaged gradient both replicas apply in this step (norm-wise, like the single-GPU gradient tests: a shard of
+            # three rows makes the BatchNorm backward ill-conditioned, so single elements carry per cents of relative noise)
+            for r in range(2):
+                close(got[r][f'g{s}/{k}'], grads[k], what=f'step {s} rank {r} averaged gradient {k}', rtol=2e-4, atol=1e-6, scale=sc,
+                      norm_rtol=2e-4)
         opt.step()
     skip = bn_shadowed_biases(sd.keys())
     for k, v in params.items():
         assert np.array_equal(got[0][k], got[1][k]), f'replicas differ in {k}'
         if k not in skip:
-            close(got[0][k], v.detach(), what=k, rtol=2e-4, atol=2e-5, norm_rtol=1e-4)
+            # Adam / Adagrad normalise each element's step by its own gradient history: where consecutive gradients nearly
+            # cancel, the per cents of noise above become per cents of lr. 2 % of the distance three steps can move an element
+            # is granted on top of the G8 tolerance (a wrong average would be off by the whole distance)
+            close(got[0][k], v.detach(), what=k, rtol=2e-4, atol=2e-5 + 0.02 * 3 * case['lr'], norm_rtol=1e-4)
     for r in range(2):
         for k, v in stats[r].items():
             if k not in skip:
