@@ -460,3 +460,60 @@ def test_native_plan_padding_equals_engine_plan():
             got = (ctypes.c_long * n_mod)(*[int(c) for c in raw])
             assert lib.sbr_host_pad_counts(ctypes.cast(got, ctypes.c_void_p), n_mod, R) == 0
             assert list(got) == want.tolist(), (R, n_mod)
+
+
+@pytest.mark.parametrize('name', ['split_random', 'split_cold_item'])
+def test_device_containers_built_from_reference_objects_equal_the_product_loader(name):
+    """Boundary evidence (g16, tests/golden/make_golden_boundary.py): ``DeviceTable`` / ``_csr_to_device`` / ``FullEvaluator``
+    were fed the reference's REAL ``Feature`` and ``FullEvalDataset`` objects in the build container and every buffer they
+    would upload was recorded. Here the same buffers are built from the product's own loader (load_split_dataset ->
+    HostFeature) and from the HostFeatures SingleBranchNet adds itself: layouts, id -> row maps, category folds, padded tag
+    matrices (as tag sets per row: the reference pads in set order), CSR arrays, exclusion and label CSRs are identical."""
+    import json
+    import sibrar_amd as S
+    from importlib import import_module
+    evaluation = import_module('sibrar---single-branch-recommender_amd.evaluation')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(here, 'g16_boundary.npz'), allow_pickle=False)
+    meta = json.load(open(os.path.join(here, 'g16_boundary.json')))
+    fdefs = dict(user_feature_definitions=[{'name': 'gender', 'type': 'categorical'}, {'name': 'age', 'type': 'discrete'}],
+                 item_feature_definitions=[{'name': 'genres', 'type': 'tag', 'tag_split_sep': '|'}, {'name': 'text', 'type': 'vector'}])
+    n_tables = 0
+    for split in ('train', 'val', 'test'):
+        ds = S.load_split_dataset(os.path.join(here, name), split, n_negative_samples=3, **fdefs)
+        feats = {('user', k): f for k, f in ds.user_features.items()}
+        feats.update({('item', k): f for k, f in ds.item_features.items()})
+        feats[('user', 'interactions')] = S.HostFeature('interactions', 'csr', ds.user_sampling_matrix_train)
+        feats[('user', 'user_embedding')] = S.HostFeature('user_embedding', 'categorical', np.arange(ds.n_users), n_categories=ds.n_users)
+        feats[('item', 'interactions')] = S.HostFeature('interactions', 'csr', ds.item_sampling_matrix_train)
+        feats[('item', 'item_embedding')] = S.HostFeature('item_embedding', 'categorical', np.arange(ds.n_items), n_categories=ds.n_items)
+        for (ent, k), f in feats.items():
+            p = f'{name}/{split}/{ent}/{k}'
+            t, m = S.DeviceTable(f), meta[p]
+            assert (t.kind, int(t.dim), int(t.n_rows)) == (m['kind'], m['dim'], m['n_rows']), p
+            for attr in ('n_categories', 'pad', 'T', 'binary'):
+                assert (attr in m) == hasattr(t, attr) and (attr not in m or int(getattr(t, attr)) == m[attr]), (p, attr)
+            for buf in ('values', 'tags', 'indptr', 'indices', 'data', 'rowmap'):
+                got = getattr(t, buf, None)
+                assert (got is not None) == (f'{p}/{buf}' in z.files), (p, buf)
+                if got is None:
+                    continue
+                want = z[f'{p}/{buf}']
+                if buf == 'tags':
+                    assert got.shape == want.shape
+                    for a, b in zip(got.numpy(), want):
+                        assert sorted(a.tolist()) == sorted(b.tolist()), p
+                elif got.dtype.is_floating_point:
+                    assert np.allclose(got.numpy(), want), (p, buf)
+                else:
+                    assert np.array_equal(got.numpy(), want), (p, buf)
+            n_tables += 1
+        if split != 'train':
+            p = f'{name}/{split}'
+            ip, ix = evaluation._csr_to_device(ds.exclude_data, 'cpu')
+            assert np.array_equal(ip.numpy(), z[p + '/exclude/indptr']) and np.array_equal(ix.numpy(), z[p + '/exclude/indices'])
+            lp, lx = S.FullEvaluator(dataset=ds)._labels('cpu')
+            assert np.array_equal(lp.numpy(), z[p + '/labels/indptr']) and np.array_equal(lx.numpy(), z[p + '/labels/indices'])
+            assert np.array_equal(np.asarray(ds.items_in_split), z[p + '/items_in_split'])
+            assert np.array_equal(np.asarray(ds.users_in_split), z[p + '/users_in_split'])
+    assert n_tables == 24
