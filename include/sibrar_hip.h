@@ -62,6 +62,14 @@ int sbr_gemm_nt_splitk_f32(const float* A, long lda, const int* a_idx, const flo
 long sbr_gemm_tn_f32_workspace(int M, int N, int K);
 int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C, long ldc,
                     int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
+/* The same product with the reduction deferred: sbr_gemm_tn_f32_slabs writes only the partial slabs (the workspace then belongs to
+ * the product; *splits_out, a HOST int, receives the slab count) and sbr_splitk_reduce_multi sums the slabs of up to 8 products in
+ * the same fixed order with ONE launch (a training step needs its weight gradients only at the optimizer). slabs / outs: HOST
+ * arrays of device pointers; ldcs / Ms / Ns / splits: HOST arrays. */
+int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
+                          void* workspace, long workspace_bytes, int* splits_out, void* stream);
+int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms, const int* Ns,
+                            const int* splits, void* stream);
 
 /* HOST function (no device work): numpy's legacy `np.random.randint(0, high, size=n)` on a caller-owned MT19937 state
  * (key[624] + position from np.random.get_state(), advanced in place) — the draws of the default negative-sampling collate

@@ -448,18 +448,14 @@ extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
   return (long)tn_splits(M, N, K) * M * N * (long)sizeof(float);
 }
 
-// C[m, n] = sum_k A[ak(k), m] * B[bk(k), n]  (C is overwritten). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes.
-extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx,
-                               float* C, long ldc, int M, int N, int K, void* workspace, long workspace_bytes, void* stream) {
-  SBR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sbr_gemm_tn_f32: negative size");
-  if (M == 0 || N == 0) return SBR_OK;
-  SBR_REQUIRE(A && B && C, "sbr_gemm_tn_f32: null operand");
-  hipStream_t s = (hipStream_t)stream;
+// slab pass of the TN product: partial tiles slab[z][M][N] for z < *splits_out (plain stores), no reduction
+static int tn_slabs(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
+                    void* workspace, long workspace_bytes, int* splits_out, hipStream_t s) {
   int splits = tn_splits(M, N, K);
   SBR_REQUIRE(workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float), "sbr_gemm_tn_f32: workspace too small");
   GemmArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.bias = nullptr;
-  g.C = C; g.ldc = ldc; g.c_idx = nullptr; g.M = M; g.N = N; g.K = K; g.act = SBR_ACT_NONE;
+  g.C = nullptr; g.ldc = N; g.c_idx = nullptr; g.M = M; g.N = N; g.K = K; g.act = SBR_ACT_NONE;
   g.vecA = aligned16(A, lda); g.vecB = aligned16(B, ldb);
   g.atomic = 0;
   g.slab = (float*)workspace;
@@ -468,9 +464,81 @@ extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const
   g.splits = splits;
   int rc = K >= BK ? sbr_gemm_ring_launch(2, g, s) : -1;
   if (rc < 0) rc = launch<2, 2, 1, 2, true, true>(g, splits, s);
+  *splits_out = splits;
+  return rc;
+}
+
+// C[m, n] = sum_k A[ak(k), m] * B[bk(k), n]  (C is overwritten). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes.
+extern "C" int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx,
+                               float* C, long ldc, int M, int N, int K, void* workspace, long workspace_bytes, void* stream) {
+  SBR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sbr_gemm_tn_f32: negative size");
+  if (M == 0 || N == 0) return SBR_OK;
+  SBR_REQUIRE(A && B && C, "sbr_gemm_tn_f32: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  int splits = 0;
+  const int rc = tn_slabs(A, lda, a_idx, B, ldb, b_idx, M, N, K, workspace, workspace_bytes, &splits, s);
   if (rc) return rc;
   const long total = (long)M * N;
-  splitk_reduce_kernel<<<sbr_cdiv(total, 32), 256, 0, s>>>(g.slab, C, ldc, M, N, splits);
+  splitk_reduce_kernel<<<sbr_cdiv(total, 32), 256, 0, s>>>((const float*)workspace, C, ldc, M, N, splits);
   SBR_CHECK_LAUNCH("sbr_gemm_tn_f32/reduce");
+  return SBR_OK;
+}
+
+// The same product with the reduction DEFERRED: only the partial slabs are written (the workspace then belongs to this product
+// until sbr_splitk_reduce_multi has consumed it); *splits_out (host) receives the number of slabs. Weight gradients are not
+// needed before the optimizer, so a training step sums the slabs of all its dW products with ONE launch at the end of the
+// backward pass (three reducer launches of 8 - 12 us each, latency-bound at 8 - 47 MB, become one).
+extern "C" int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M,
+                                     int N, int K, void* workspace, long workspace_bytes, int* splits_out, void* stream) {
+  SBR_REQUIRE(M >= 1 && N >= 1 && K >= 1 && splits_out, "sbr_gemm_tn_f32_slabs: bad arguments");
+  SBR_REQUIRE(A && B, "sbr_gemm_tn_f32_slabs: null operand");
+  return tn_slabs(A, lda, a_idx, B, ldb, b_idx, M, N, K, workspace, workspace_bytes, splits_out, (hipStream_t)stream);
+}
+
+struct SplitkMulti {
+  const float* slab[8];
+  float* C[8];
+  long ldc[8];
+  int M[8], N[8], splits[8];
+};
+
+// splitk_reduce_kernel for up to 8 products at once: blockIdx.y selects the product (same fixed summation order)
+__global__ void splitk_reduce_multi_kernel(SplitkMulti a) {
+  __shared__ float part[8][32];
+  const int q = blockIdx.y;
+  const int e_local = threadIdx.x & 31, zg = threadIdx.x >> 5;
+  const long total = (long)a.M[q] * a.N[q];
+  const long e = blockIdx.x * 32L + e_local;
+  if (blockIdx.x * 32L >= total) return;                    // uniform per workgroup
+  const float* slab = a.slab[q];
+  const int splits = a.splits[q];
+  float acc = 0.f;
+  if (e < total)
+    for (int z = zg; z < splits; z += 8) acc += slab[z * total + e];
+  part[zg][e_local] = acc;
+  __syncthreads();
+  if (zg == 0 && e < total) {
+    float v = part[0][e_local];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) v += part[g][e_local];
+    a.C[q][(e / a.N[q]) * a.ldc[q] + (e % a.N[q])] = v;
+  }
+}
+
+// slabs / outs: HOST arrays of device pointers; ldcs, Ms, Ns, splits: HOST arrays (copied into the launch)
+extern "C" int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
+                                       const int* Ns, const int* splits, void* stream) {
+  if (count == 0) return SBR_OK;
+  SBR_REQUIRE(count >= 1 && count <= 8 && slabs && outs && ldcs && Ms && Ns && splits, "sbr_splitk_reduce_multi: 1..8 products per call");
+  SplitkMulti a;
+  long most = 0;
+  for (int q = 0; q < count; ++q) {
+    SBR_REQUIRE(slabs[q] && outs[q] && Ms[q] >= 1 && Ns[q] >= 1 && splits[q] >= 1, "sbr_splitk_reduce_multi: bad entry %d", q);
+    a.slab[q] = (const float*)slabs[q]; a.C[q] = (float*)outs[q]; a.ldc[q] = ldcs[q]; a.M[q] = Ms[q]; a.N[q] = Ns[q]; a.splits[q] = splits[q];
+    const long total = (long)Ms[q] * Ns[q];
+    most = total > most ? total : most;
+  }
+  splitk_reduce_multi_kernel<<<dim3(sbr_cdiv(most, 32), count), 256, 0, (hipStream_t)stream>>>(a);
+  SBR_CHECK_LAUNCH("sbr_splitk_reduce_multi");
   return SBR_OK;
 }

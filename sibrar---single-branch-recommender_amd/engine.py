@@ -100,6 +100,7 @@ class _EntityRun:
         self.fuse_tail = False
         self.tail = None             # (z, mean, rstd) of the current step when the tail is fused
         self.fold = os.environ.get('SBR_FOLD_COLSUM', '1') != '0'
+        self.tn = ops.DeferredTN() if os.environ.get('SBR_DEFER_SPLITK', '1') != '0' else None   # dW slabs summed by one launch
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def plan(self, draw: Tuple[np.ndarray, list], pad: bool = False):
@@ -314,7 +315,10 @@ class _EntityRun:
                 bias_done = True
             else:
                 dz = ops.act_grad(d, y, act) if act else d
-            ops.matmul_tn(dz, x, out=_grad_of(w))
+            if self.tn is not None:
+                self.tn.matmul_tn(id(lin), dz, x, out=_grad_of(w))
+            else:
+                ops.matmul_tn(dz, x, out=_grad_of(w))
             if not bias_done:
                 ops.colsum(dz, out=_grad_of(lin.bias))
             last = li == len(self.layers) - 1
@@ -334,7 +338,9 @@ class _EntityRun:
         for (fe, o, n), hs in zip(self.entries, self.hidden):
             ps = fe.front_params()
             fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps],
-                              pending=pending)
+                              pending=pending, tn=self.tn)
+        if self.tn is not None:
+            self.tn.finish()
         if pending:
             ops.colred_finish(pending)
 

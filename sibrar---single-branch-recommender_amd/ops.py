@@ -149,6 +149,48 @@ def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None, out=None):
     return out
 
 
+class DeferredTN:
+    """dW products of one backward pass whose split-K slabs are summed by ONE launch at the end (sbr_splitk_reduce_multi).
+    Every product keeps its own persistent slab workspace under a caller-chosen key: captured step graphs hold the addresses, so an
+    outgrown workspace is retired (kept allocated), never freed."""
+
+    def __init__(self):
+        self.ws = {}                 # key -> float32 workspace tensor
+        self.pending = []            # (workspace, out, M, N, splits)
+
+    def matmul_tn(self, key, dz, x, a_idx=None, b_idx=None, n_rows=None, out=None):
+        import ctypes
+        R = n_rows if n_rows is not None else dz.shape[0]
+        M, N = dz.shape[1], x.shape[1]
+        if R == 0:
+            return out.zero_()
+        need = lib().sbr_gemm_tn_f32_workspace(M, N, R)
+        ws = self.ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            if ws is not None:
+                _WS_RETIRED.append(ws)
+            ws = self.ws[key] = torch.empty(max((need + 3) // 4, 2 * ws.numel() if ws is not None else 0), device=dz.device,
+                                            dtype=torch.float32)
+        splits = ctypes.c_int(0)
+        _timed(('gemm_f32', 2, M, N, R, a_idx is not None or b_idx is not None),
+               lambda: call('sbr_gemm_tn_f32_slabs', ptr(dz), dz.stride(0), ptr(a_idx), ptr(x), x.stride(0), ptr(b_idx), M, N, R,
+                            ptr(ws), ws.numel() * 4, ctypes.cast(ctypes.pointer(splits), ctypes.c_void_p), stream()))
+        self.pending.append((ws, out, M, N, splits.value))
+        return out
+
+    def finish(self):
+        import ctypes
+        for lo in range(0, len(self.pending), 8):
+            part = self.pending[lo:lo + 8]
+            n = len(part)
+            arr = lambda ct, vals: ctypes.cast((ct * n)(*vals), ctypes.c_void_p)
+            call('sbr_splitk_reduce_multi', n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]),
+                 arr(ctypes.c_void_p, [p[1].data_ptr() for p in part]), arr(ctypes.c_long, [p[1].stride(0) for p in part]),
+                 arr(ctypes.c_int, [p[2] for p in part]), arr(ctypes.c_int, [p[3] for p in part]),
+                 arr(ctypes.c_int, [p[4] for p in part]), stream())
+        self.pending = []
+
+
 _COLSUM_WS = {}
 
 

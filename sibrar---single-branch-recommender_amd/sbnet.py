@@ -298,12 +298,13 @@ class FeatureEmbedding(nn.Module):
             h = dst
         return hidden
 
-    def front_backward(self, p, hidden, rows, n, out, dout, slots, grad_out=None, pending=None):
+    def front_backward(self, p, hidden, rows, n, out, dout, slots, grad_out=None, pending=None, tn=None):
         """Gradients of this modality's parameters. ``grad_out`` (optional): tensors to write into instead of fresh ones —
         lookup-table gradients are ACCUMULATED into them (they must be zero-initialised), dense ones are overwritten.
         ``pending`` (optional list, needs ``grad_out``): the bias gradients are left pending as column sums folded into the
         activation-derivative kernels — (workspace, bias gradient) pairs are appended and the caller completes them with
-        ``ops.colred_finish`` (one launch for all layers of a step instead of two per bias)."""
+        ``ops.colred_finish`` (one launch for all layers of a step instead of two per bias). ``tn`` (optional ``ops.DeferredTN``,
+        needs ``grad_out``): the weight-gradient products only write their split-K slabs; the caller sums them with ``tn.finish()``."""
         t = self._table
         st = stream()
         if self.kind == 'categorical':
@@ -349,9 +350,15 @@ class FeatureEmbedding(nn.Module):
                      ptr(dWt), dWt.stride(0), n, W.shape[0], st)
                 grads[0] = dWt.t()
             elif l == 0:
-                grads[0] = ops.matmul_tn(dz, t.values, b_idx=rows, n_rows=n, out=go[0])
+                if tn is not None and go[0] is not None:
+                    grads[0] = tn.matmul_tn((id(self), 0), dz, t.values, b_idx=rows, n_rows=n, out=go[0])
+                else:
+                    grads[0] = ops.matmul_tn(dz, t.values, b_idx=rows, n_rows=n, out=go[0])
             else:
-                grads[2 * l] = ops.matmul_tn(dz, hidden[l - 1], n_rows=n, out=go[2 * l])
+                if tn is not None and go[2 * l] is not None:
+                    grads[2 * l] = tn.matmul_tn((id(self), l), dz, hidden[l - 1], n_rows=n, out=go[2 * l])
+                else:
+                    grads[2 * l] = ops.matmul_tn(dz, hidden[l - 1], n_rows=n, out=go[2 * l])
                 dh = ops.matmul_nn(dz, W if W.stride(1) == 1 else W.contiguous())
                 dz = dz_of(dh, hidden[l - 1], l - 1)
         return grads
