@@ -138,6 +138,34 @@ class pin_stream:
         return False
 
 
+class use_stream:
+    """Context manager: issue the kernel calls (and torch ops) inside on ``torch_stream`` — a second branch of a step. ``fork``
+    makes the branch start behind everything queued on the current stream so far; ``join()`` afterwards makes the current stream
+    wait for the branch. Inside a hipGraph capture this records a parallel branch of the graph."""
+
+    def __init__(self, torch_stream, fork: bool = True):
+        self.s, self.fork = torch_stream, fork
+
+    def __enter__(self):
+        import torch
+        self.cur = torch.cuda.current_stream()
+        if self.fork:
+            self.s.wait_stream(self.cur)
+        self.prev = _STREAM.value
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        _STREAM.value = self.s.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM.value = self.prev
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        self.cur.wait_stream(self.s)
+
+
 def to_device(t, device):
     """Host -> device copy that is asynchronous only for PINNED sources. An "async" copy from pageable memory may read the
     host buffer after the call returned (observed on ROCm: a temporary staging tensor was recycled before its copy ran — garbage

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from ._lib import call, pin_stream, ptr, to_device
+from ._lib import call, pin_stream, ptr, to_device, use_stream
 from .config import EmbeddingRegularizationType
 from .losses import RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy, RecSampledSoftmaxLoss
 from .sbnet import FeatureEmbedding, SingleBranchNet, SingleBranchNetEntity, resolve_rows
@@ -100,6 +100,11 @@ class _EntityRun:
         self.fuse_tail = False
         self.tail = None             # (z, mean, rstd) of the current step when the tail is fused
         self.fold = os.environ.get('SBR_FOLD_COLSUM', '1') != '0'
+        # lookup-type modalities (embedding / tag bag: HBM gathers and float-atomic scatters, no allocation, rows disjoint from the
+        # other modalities') run as a parallel branch next to the dense projectors' GEMMs: a second stream, i.e. a second
+        # branch of the captured graph (c2: the 43 us item-table scatter and the 12 us lookup hide behind 99 / 96 us of MFMA work)
+        self.branch = os.environ.get('SBR_BRANCH_LOOKUPS', '1') != '0'
+        self._side = None
         self.tn = ops.DeferredTN() if os.environ.get('SBR_DEFER_SPLITK', '1') != '0' else None   # dW slabs summed by one launch
 
     # ---- forward -----------------------------------------------------------------------------------------------------
@@ -164,7 +169,22 @@ class _EntityRun:
         rows, _ = resolve_rows(idx_flat, k, slots, offs, tables, ent._idx_err)
         self.entries, self.rows, self.slots, self.R, self.k, self.shape = entries, rows, slots, R, k, tuple(idx.shape)
         x0 = a.f32(R + 1 if padded else R, self.C)      # row R: landing row of the padded launches
-        self.hidden = [fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n]) for fe, o, n in entries]
+        light = [fe.kind in ('categorical', 'tag') for fe, _, _ in entries]
+        fork = self.branch and any(light) and not all(light)
+        self.hidden = [None] * len(entries)
+        if fork:
+            if self._side is None:
+                self._side = torch.cuda.Stream(x0.device)
+            with use_stream(self._side) as br:
+                for q, (fe, o, n) in enumerate(entries):
+                    if light[q]:
+                        self.hidden[q] = fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n])
+        for q, (fe, o, n) in enumerate(entries):
+            if not (fork and light[q]):
+                self.hidden[q] = fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n])
+        if fork:
+            br.join()
+        self._forked = fork
         self.x0 = x0
         x = x0[:R]
         if self.normalize:
@@ -335,7 +355,17 @@ class _EntityRun:
         if d.data_ptr() != dx0.data_ptr():               # no layer at all: the incoming gradient is the matrix gradient
             torch.mul(d, 1.0, out=dx0[:R])                # a kernel node, not a memcpy node (see DESIGN.md §5 on memset nodes)
         d = dx0
+        br = None
+        if self._forked:
+            with use_stream(self._side) as br:
+                for (fe, o, n), hs in zip(self.entries, self.hidden):
+                    if fe.kind in ('categorical', 'tag'):
+                        ps = fe.front_params()
+                        fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n],
+                                          grad_out=[_grad_of(p) for p in ps])
         for (fe, o, n), hs in zip(self.entries, self.hidden):
+            if br is not None and fe.kind in ('categorical', 'tag'):
+                continue
             ps = fe.front_params()
             fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps],
                               pending=pending, tn=self.tn)
@@ -343,6 +373,8 @@ class _EntityRun:
             self.tn.finish()
         if pending:
             ops.colred_finish(pending)
+        if br is not None:
+            br.join()
 
 
 class _PlainRun:
