@@ -100,10 +100,13 @@ class _EntityRun:
         self.fuse_tail = False
         self.tail = None             # (z, mean, rstd) of the current step when the tail is fused
         self.fold = os.environ.get('SBR_FOLD_COLSUM', '1') != '0'
-        # lookup-type modalities (embedding / tag bag: HBM gathers and float-atomic scatters, no allocation, rows disjoint from the
-        # other modalities') run as a parallel branch next to the dense projectors' GEMMs: a second stream, i.e. a second
-        # branch of the captured graph (c2: the 43 us item-table scatter and the 12 us lookup hide behind 99 / 96 us of MFMA work)
-        self.branch = os.environ.get('SBR_BRANCH_LOOKUPS', '1') != '0'
+        # OPT-IN experiment (SBR_BRANCH_LOOKUPS=1), measured SLOWER: lookup-type modalities (embedding / tag bag: HBM gathers and
+        # float-atomic scatters, no allocation, rows disjoint from the other modalities') as a parallel branch next to the dense
+        # projectors' GEMMs — a second stream, i.e. a second branch of the captured graph — so that the 43 us item-table scatter and
+        # the 12 us lookup of c2 would hide behind 99 / 96 us of MFMA work. Results are identical (all tests pass), but a replayed
+        # hipGraph with two fork / join pairs takes 1.50 ms per step instead of 0.78 (B = 256: 1.3 instead of 0.31 ms) on ROCm
+        # 7.2: cross-branch edges of a graph are far more expensive than the work they would overlap. Linear graphs only.
+        self.branch = os.environ.get('SBR_BRANCH_LOOKUPS', '0') == '1'
         self._side = None
         self.tn = ops.DeferredTN() if os.environ.get('SBR_DEFER_SPLITK', '1') != '0' else None   # dW slabs summed by one launch
 
