@@ -232,6 +232,18 @@ def dominant_gemm(timings, steps, batch=None):
         return None
     (_, mode, M, N, K, gathered), tot, ts = best
     avg_ms = tot / len(ts)
+    reduce_ms = 0.0
+    if mode == 2:
+        # the split-K slabs of all dW products of a step are summed by ONE shared launch (sbr_splitk_reduce_multi): this
+        # product is charged its share of that launch by slab bytes, so that `achieved` stays "kernel + its reduction"
+        for key, rts in timings.items():
+            if key[0] != 'splitk_reduce_multi' or not rts:
+                continue
+            mine = sum(m * n * z for (m, n, z) in key[1] if (m, n) == (M, N))
+            total = sum(m * n * z for (m, n, z) in key[1])
+            if mine:
+                reduce_ms += (sum(rts) / len(rts)) * mine / total / max(1, sum(1 for (m, n, z) in key[1] if (m, n) == (M, N)))
+        avg_ms += reduce_ms
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic(mode, M, N, K, batch)
@@ -240,8 +252,9 @@ def dominant_gemm(timings, steps, batch=None):
             'traffic_source': None if traffic is None else f'HBM bytes per launch from {src} (rocprofv3 --pmc FETCH_SIZE and --pmc '
                               f'WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
             'kernel': f'fp32 MFMA GEMM (gemm_ring_kernel) mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
-                      + (' + split-K slab reduce' if mode == 2 else ''),
-            'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps, 4),
+                      + (f' + its share ({reduce_ms * 1e3:.1f} us, by slab bytes) of the step\'s shared split-K slab reduction '
+                         f'(splitk_reduce_multi_kernel)' if mode == 2 else ''),
+            'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps + reduce_ms * len(ts) / steps, 4),
             'timing': 'HIP events around every launch of this kernel over K plain-launch steps run right after the timed '
                       'region (the timed region replays a hipGraph, which cannot carry per-kernel events); each of those steps '
                       'is queued behind a spin kernel so that its kernels run back to back as they do in the replay',

@@ -184,10 +184,11 @@ class DeferredTN:
             part = self.pending[lo:lo + 8]
             n = len(part)
             arr = lambda ct, vals: ctypes.cast((ct * n)(*vals), ctypes.c_void_p)
-            call('sbr_splitk_reduce_multi', n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]),
+            # timed as one launch; the key carries every product's (M, N, slabs) so that a reader can apportion it by slab bytes
+            _timed(('splitk_reduce_multi', tuple((p[2], p[3], p[4]) for p in part)), lambda: call('sbr_splitk_reduce_multi', n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]),
                  arr(ctypes.c_void_p, [p[1].data_ptr() for p in part]), arr(ctypes.c_long, [p[1].stride(0) for p in part]),
                  arr(ctypes.c_int, [p[2] for p in part]), arr(ctypes.c_int, [p[3] for p in part]),
-                 arr(ctypes.c_int, [p[4] for p in part]), stream())
+                 arr(ctypes.c_int, [p[4] for p in part]), stream()))
         self.pending = []
 
 
