@@ -71,6 +71,16 @@ int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx, const floa
 int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms, const int* Ns,
                             const int* splits, void* stream);
 
+/* Weights-resident variant for the shared MLP's own products (N = K = 128, no gathers): every wave keeps its half of the 128 x 128
+ * weight in registers, only A streams through LDS (csrc/gemm_wres_f32.hip); bit-identical to sbr_gemm_f32 on the same operands.
+ * mode 0 (NT): C = act(A W^T + bias) — nn.Linear forward, modules/polylinear.py:51,63-72; mode 1 (NN): C = A W — its autograd
+ * w.r.t. the input. Y != NULL (mode 1): C = (A W) * act'(Y), the gradient at the pre-activation of the layer in front whose OUTPUT
+ * is Y, and colsum_ws (17 * 128 doubles, contract of sbr_colsum; may be NULL) receives the pending column sums of C — that layer's
+ * bias gradient, completed by sbr_colred_finish. */
+int sbr_gemm_wres_supported(long M, int N, int K);
+int sbr_gemm_wres_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
+                      int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream);
+
 /* HOST function (no device work): numpy's legacy `np.random.randint(0, high, size=n)` on a caller-owned MT19937 state
  * (key[624] + position from np.random.get_state(), advanced in place) — the draws of the default negative-sampling collate
  * (data/dataloader.py:154-198, np.random.choice(items_in_split, n) on the global RandomState). Bit-identical values and final

@@ -324,10 +324,14 @@ class _EntityRun:
         if self.padded:
             dx0[R].zero_()
         tail_ops = (self.seed is not None) + bool(self.normalize)
-        for li, ((lin, bn, act), (x, z, y, mean, rstd)) in enumerate(zip(reversed(self.layers), reversed(self.acts))):
+        chain = list(zip(reversed(self.layers), reversed(self.acts)))
+        pre = None                                     # dz of the coming layer when the previous NN product already produced it
+        for li, ((lin, bn, act), (x, z, y, mean, rstd)) in enumerate(chain):
             w = lin.weight
             bias_done = folded_last and li == 0
-            if bn is not None:
+            if pre is not None:
+                dz, pre, bias_done = pre, None, True
+            elif bn is not None:
                 dz = self._bn_bwd(bn, d, y, z, mean, rstd, act)
             elif act and pending is not None and ops.colsum_supported(d.shape[1]):
                 ws_l = self._fold_ws(lin, d.shape[1])
@@ -345,7 +349,21 @@ class _EntityRun:
             if not bias_done:
                 ops.colsum(dz, out=_grad_of(lin.bias))
             last = li == len(self.layers) - 1
-            d = ops.matmul_nn(dz, w, out=dx0[:R] if (last and not tail_ops) else a.f32(R, w.shape[1]))
+            if not last:
+                # the layer in front (x is its output): Linear + activation without a BatchNorm of its own -> the NN product
+                # applies the activation derivative and accumulates that layer's bias gradient in its epilogue
+                lin_b, bn_b, act_b = chain[li + 1][0]
+                nxt = a.f32(R, w.shape[1])
+                if bn_b is None and act_b and pending is not None and lin_b.bias is not None \
+                        and ops.matmul_nn_actgrad_ok(dz, w, x, nxt) and ops.colsum_supported(w.shape[1]):
+                    ws_b = self._fold_ws(lin_b, w.shape[1])
+                    pre = ops.matmul_nn_actgrad(dz, w, x, act_b, nxt, ws_b)
+                    pending.append((ws_b, _grad_of(lin_b.bias)))
+                    d = None
+                    continue
+                d = ops.matmul_nn(dz, w, out=nxt)
+            else:
+                d = ops.matmul_nn(dz, w, out=dx0[:R] if not tail_ops else a.f32(R, w.shape[1]))
         if self.seed is not None:
             tail_ops -= 1
             dd = dx0[:R] if not tail_ops else a.f32(R, self.C)

@@ -75,6 +75,19 @@ def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, 
                         ptr(c_idx), M, N, K, act, atomic, stream()))
 
 
+import os as _os
+
+_WRES = _os.environ.get('SBR_GEMM_WRES', '1') != '0'
+
+
+def _wres_ok(M, N, K, *tensors) -> bool:
+    """The weights-resident kernel (csrc/gemm_wres_f32.hip) takes the shared MLP's own products: N = K = 128, no gathers,
+    16-byte aligned rows."""
+    if not _WRES or M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
+        return False
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
+
+
 def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None):
     """out[ci(m)] = act(x[ai(m)] @ W^T + bias). W: [N, K] with arbitrary row stride (column-major weights are handled by
     the caller through csr kernels, not here)."""
@@ -82,6 +95,11 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
     N, K = W.shape
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if a_idx is None and c_idx is None and _wres_ok(M, N, K, x, W, out):
+        _timed(('gemm_f32', 0, M, N, K, False),
+               lambda: call('sbr_gemm_wres_f32', 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                            act, None, 0, None, stream()))
+        return out
     ws_bytes = lib().sbr_gemm_nt_splitk_workspace(M, N, K) if M > 0 else 0
     if ws_bytes > 0:
         # few output tiles, long K (the modality projectors at small batches): K split over workgroups, deterministic reduce
@@ -100,7 +118,28 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None, out=None):
     K, N = W.shape
     if out is None:
         out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
+    if a_idx is None and _wres_ok(M, N, K, dz, W, out):
+        _timed(('gemm_f32', 1, M, N, K, False),
+               lambda: call('sbr_gemm_wres_f32', 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, 0,
+                            None, 0, None, stream()))
+        return out
     gemm(1, dz, dz.stride(0), a_idx, W, W.stride(0), None, None, out, out.stride(0), None, M, N, K, 0, 0)
+    return out
+
+
+def matmul_nn_actgrad_ok(dz, W, y, out) -> bool:
+    K, N = W.shape
+    return _wres_ok(dz.shape[0], N, K, dz, W, y, out)
+
+
+def matmul_nn_actgrad(dz, W, y, act: int, out, colsum_ws=None):
+    """out = (dz @ W) * act'(y) — the gradient at the pre-activation of the layer in front (whose OUTPUT is y) in one kernel;
+    ``colsum_ws``: that layer's bias gradient is left pending there (``colred_finish``). Check ``matmul_nn_actgrad_ok`` first."""
+    M = dz.shape[0]
+    K, N = W.shape
+    _timed(('gemm_f32', 1, M, N, K, False),
+           lambda: call('sbr_gemm_wres_f32', 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, act,
+                        ptr(y), y.stride(0), ptr(colsum_ws), stream()))
     return out
 
 

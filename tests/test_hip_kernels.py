@@ -625,3 +625,33 @@ def test_merge_topk_kernel_equals_the_host_merge(W, Bu, k):
     assert torch.equal(out_idx.cpu(), ri.int())
     got, want = out_val.cpu(), rv
     assert torch.equal(torch.isinf(got), torch.isinf(want)) and torch.equal(got[~torch.isinf(got)], want[~torch.isinf(want)])
+
+
+@pytest.mark.parametrize('M', [1, 63, 64, 200, 4097, 90112])
+def test_weights_resident_gemm_is_bit_identical_to_the_ring_kernel(M, monkeypatch):
+    """sbr_gemm_wres_f32 (N = K = 128: the weight in registers, only A streamed) == sbr_gemm_f32 bit for bit — NT with bias and
+    every activation the step uses, NN — including a ragged last tile; and its fused backward epilogue (activation derivative of a
+    second matrix + the column sums of the result) == NN product -> sbr_act_grad_gather -> sbr_colsum."""
+    ops = S().ops
+    x, w, b = _rand(M, 128, seed=41).to(DEV), (_rand(128, 128, seed=42) / 8).to(DEV), _rand(128, seed=43).to(DEV)
+    y_act = torch.relu(_rand(M, 128, seed=44)).to(DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, '_WRES', flag)
+        res[flag] = [ops.linear_nt(x, w, b, act) for act in (0, 1, 2)] + [ops.matmul_nn(x, w)]
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(a_, b_)
+    ref = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    close(res[True][0].cpu(), ref, rtol=1e-4, atol=1e-5, what='nt', norm_rtol=2e-6, scale=float(ref.abs().max()))
+    # fused epilogue
+    monkeypatch.setattr(ops, '_WRES', True)
+    out = torch.empty(M, 128, device=DEV)
+    ws = ops.new_colsum_ws(x.device, 128)
+    assert ops.matmul_nn_actgrad_ok(x, w, y_act, out)
+    ops.matmul_nn_actgrad(x, w, y_act, 1, out, ws)
+    db = torch.empty(128, device=DEV)
+    ops.colred_finish([(ws, db)])
+    unf = ops.act_grad(res[False][3], y_act, 1)
+    assert torch.equal(out, unf)
+    close(db.cpu(), ops.colsum(unf).cpu(), rtol=1e-5, atol=1e-5, what='folded bias gradient', norm_rtol=1e-6)
+    assert float(ws.abs().max()) == 0.0                       # the finishing launch left the workspace zeroed
