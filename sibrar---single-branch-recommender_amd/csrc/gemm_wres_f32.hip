@@ -18,11 +18,13 @@
 //     gradient of that layer), accumulated per workgroup over all its tiles and flushed once into a column-reduction workspace.
 // Persistent: 2 workgroups per CU (64 KB of LDS, ~200 VGPRs), workgroup b walks tiles b, b + grid, ...
 #include "gemm_args.h"
+#include <type_traits>
+#include <stdlib.h>
 
 #define WR_N 128
 #define WR_K 128
 #define WR_BM 64
-#define WR_COUNTED_WAIT 0
+#define WR_COUNTED_WAIT 1
 #define WR_STAGE (WR_BM * WR_K * 4)          // 32 KB: four slab images [64 rows][8 chunks of 16 B], chunk p of row r at p ^ ((r >> 1) & 7)
 
 __device__ __attribute__((aligned(16))) float wr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-range chunks
@@ -59,6 +61,24 @@ __global__ __launch_bounds__(256, 2) void gemm_wres_kernel(WresArgs g, int n_til
   if (n_mine == 0) return;
   const float* zero = wr_zero_chunk;
 
+  // ---- A tile issue: 8 chunks of 16 bytes per thread per tile (2 per slab image) ----------------------------------------------
+  auto issue = [&](int tile, int stage) {
+    const long m0 = (long)tile * WR_BM;
+    unsigned char* st = smem + stage * WR_STAGE + wave * 1024;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = i * 256 + t, r = e >> 3, p = e & 7;
+        const long gm = m0 + r;
+        const float* src = gm < g.M ? g.A + gm * g.lda + sl * 32 + ((p ^ ((r >> 1) & 7)) << 2) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(st + sl * 8192 + i * 4096), 16, 0, 0);
+      }
+    }
+  };
+  issue(blockIdx.x, 0);                                        // the first tile travels while the weight is read
+
   // ---- this wave's half of the weight, as MFMA B operands: breg[j][q] = (W[n][8q + 4 half + s])_{s = 0..3}, n = 64 wn + 32 j + l31
   float4 breg[2][16];
 #pragma unroll
@@ -79,44 +99,39 @@ __global__ __launch_bounds__(256, 2) void gemm_wres_kernel(WresArgs g, int n_til
   if constexpr (EPI == 0) {
     if (g.bias) { bj[0] = g.bias[wn * 64 + l31]; bj[1] = g.bias[wn * 64 + 32 + l31]; }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // ordinary loads are done before the DMA pipeline starts
-
-  // ---- A tile issue: 8 chunks of 16 bytes per thread per tile (2 per slab image) ----------------------------------------------
-  auto issue = [&](int tile, int stage) {
-    const long m0 = (long)tile * WR_BM;
-    unsigned char* st = smem + stage * WR_STAGE + wave * 1024;
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = i * 256 + t, r = e >> 3, p = e & 7;
-        const long gm = m0 + r;
-        const float* src = gm < g.M ? g.A + gm * g.lda + sl * 32 + ((p ^ ((r >> 1) & 7)) << 2) : zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(st + sl * 8192 + i * 4096), 16, 0, 0);
-      }
-    }
-  };
 
   const int a_rd = (wm * 32 + l31) * 128;                      // byte offset of this lane's row inside a slab image
   const int a_sw = ((wm * 32 + l31) >> 1) & 7;
   double cs[2] = {0.0, 0.0};                                   // EPI 1: running column sums of columns 64 wn + 32 j + l31 (this lane's rows)
 
-  issue(blockIdx.x, 0);
-  bool prev_full = false;
+  // Software pipeline over tiles: the finished values of tile t wait in `pend` and are stored BETWEEN the MFMAs of tile t + 1
+  // (two stores per k-quad), so the store phase (8 us of a 40 us kernel when it ran after each tile's MFMAs: the two waves of a
+  // SIMD run the same program in lockstep and do not cover each other's store phases) disappears behind the matrix pipe.
+  f32x16 pend[2];
+  long pend_m0 = -1;                                           // tile origin of `pend` (-1: nothing pending)
+  auto store_pair = [&](int q, auto full_tag) {              // registers 2q, 2q + 1 of the pending tile (q = 0..15)
+    constexpr bool FULL = decltype(full_tag)::value;
+    float* cp = g.C + (pend_m0 + wm * 32 + 4 * half) * g.ldc + wn * 64 + l31;
+    const int rows_left = (int)(g.M - pend_m0) - wm * 32 - 4 * half;
+#pragma unroll
+    for (int e = 2 * q; e < 2 * q + 2; ++e) {
+      const int j = e >> 4, r = e & 15, lr = (r & 3) + 8 * (r >> 2);
+      if (FULL || lr < rows_left) cp[(long)lr * g.ldc + j * 32] = pend[j][r];
+    }
+  };
+
 #pragma unroll 1
   for (int it = 0; it < n_mine; ++it) {
     const int tile = blockIdx.x + it * gridDim.x;
     const long m0 = (long)tile * WR_BM;
-    // the tile's 8 DMA instructions of this thread are older than the 32 stores of the previous (interior) tile's epilogue
-    if (WR_COUNTED_WAIT && prev_full && EPI == 0) wr_wait_vmcnt<32>(); else wr_wait_vmcnt<0>();
+    // this thread's 8 DMA instructions of the tile are older than the 32 stores of the tile stored during the previous iteration
+    // (always an interior tile: a ragged tile is the last of the whole product and is stored by the flush below)
+    if (WR_COUNTED_WAIT && it >= 2 && EPI == 0) wr_wait_vmcnt<32>(); else wr_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                              // every thread's part landed; the other stage has been consumed
     asm volatile("" ::: "memory");
-    const bool full = m0 + WR_BM <= g.M;
     float4 yv[2][4];                                           // EPI 1: Y values of this lane's 32 outputs, loaded BEFORE the next DMA
     if constexpr (EPI == 1) {
-      // accumulator register r of column tile j is row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32 rows, column l31: gathered
-      // here register by register (same addresses as the stores below)
+      // accumulator register r of column tile j is row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32 rows, column l31
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -137,43 +152,86 @@ __global__ __launch_bounds__(256, 2) void gemm_wres_kernel(WresArgs g, int n_til
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    auto compute = [&](auto store_tag) {                      // the tile's 128 MFMAs (+ the pending tile's 32 stores between them)
+      constexpr bool STORE = decltype(store_tag)::value;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int sl = q >> 2, kq = q & 3;
-      const wr_v4f a = *(const wr_lds_v4f*)(As + ((sl * 8192 + a_rd + (((2 * kq + half) ^ a_sw) << 4)) >> 2));
+      for (int q = 0; q < 16; ++q) {
+        const int sl = q >> 2, kq = q & 3;
+        const wr_v4f a = *(const wr_lds_v4f*)(As + ((sl * 8192 + a_rd + (((2 * kq + half) ^ a_sw) << 4)) >> 2));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[j][q].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[j][q].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[j][q].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[j][q].w, acc[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[j][q].x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[j][q].y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[j][q].z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[j][q].w, acc[j], 0, 0, 0);
+        }
+        if constexpr (STORE) store_pair(q, std::true_type{});
       }
-    }
-    // ---- epilogue: register r of acc[j] -> row m0 + 32 wm + (r & 3) + 8 (r >> 2) + 4 half, column 64 wn + 32 j + l31
-    float* cp = g.C + (m0 + wm * 32 + 4 * half) * g.ldc + wn * 64 + l31;
-    float ts[2] = {0.f, 0.f};                                  // this tile's 16 rows per column in fp32, then into the double sums
+      // pin the issue order the source spells (hipcc otherwise sinks the stores behind the last MFMA and hoists every LDS read):
+      // the next k-quad's A fragment, this k-quad's 8 MFMAs, two stores of the pending tile
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 16; ++q) {
+        if (q < 15) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if constexpr (STORE) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+      }
+    };
+    if (EPI == 0 && pend_m0 >= 0) compute(std::true_type{});   // EPI 1 has no registers for a pending tile beside Y
+    else compute(std::false_type{});
+    // ---- finish the tile in registers: bias + activation, or the activation derivative of Y (+ this tile's column sums). Every
+    // mode decision is uniform and outside the element loops.
+    const int rows_left = (int)(g.M - m0) - wm * 32 - 4 * half;
+    auto finish = [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;            // 0: + bias, 1: relu(+ bias), 2: sbr_act(+ bias), 3: * act'(Y)
+      float ts[2] = {0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = (r & 3) + 8 * (r >> 2);
-        float v = acc[j][r];
-        if constexpr (EPI == 0) {
-          v += bj[j];
-          if (g.act == SBR_ACT_RELU) v = v > 0.f ? v : 0.f;
-          else if (g.act != SBR_ACT_NONE) v = sbr_act(v, g.act);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[j][r];
+          if constexpr (KIND <= 2) v += bj[j];
+          if constexpr (KIND == 1) v = v > 0.f ? v : 0.f;
+          if constexpr (KIND == 2) v = sbr_act(v, g.act);
+          if constexpr (KIND == 3) {
+            const float4 y4 = yv[j][r >> 2];
+            const float y = (r & 3) == 0 ? y4.x : ((r & 3) == 1 ? y4.y : ((r & 3) == 2 ? y4.z : y4.w));
+            v = v * sbr_act_grad_from_out(y, g.act);
+            if ((r & 3) + 8 * (r >> 2) < rows_left) ts[j] += v;
+          }
+          pend[j][r] = v;
+        }
+      if constexpr (KIND == 3) { cs[0] += (double)ts[0]; cs[1] += (double)ts[1]; }
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    if constexpr (EPI == 1) finish(T3{});
+    else if (g.act == SBR_ACT_NONE) finish(T0{});
+    else if (g.act == SBR_ACT_RELU) finish(T1{});
+    else finish(T2{});
+    pend_m0 = m0;
+    if constexpr (EPI == 1) {                                  // stored at once (the Y values took the pending tile's registers)
+      {
+        if (m0 + WR_BM <= g.M) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) store_pair(q, std::true_type{});
         } else {
-          const float4 y4 = yv[j][r >> 2];
-          const float y = (r & 3) == 0 ? y4.x : ((r & 3) == 1 ? y4.y : ((r & 3) == 2 ? y4.z : y4.w));
-          v = v * sbr_act_grad_from_out(y, g.act);
-        }
-        if (full || m0 + wm * 32 + 4 * half + lr < g.M) {
-          cp[(long)lr * g.ldc + j * 32] = v;
-          if constexpr (EPI == 1) ts[j] += v;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) store_pair(q, std::false_type{});
         }
       }
-    if constexpr (EPI == 1) { cs[0] += (double)ts[0]; cs[1] += (double)ts[1]; }
-    prev_full = full;
+      pend_m0 = -1;
+    }
+  }
+  // flush: the last tile of this workgroup (possibly the ragged last tile of the product)
+  if (pend_m0 >= 0) {
+    if (pend_m0 + WR_BM <= g.M) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) store_pair(q, std::true_type{});
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) store_pair(q, std::false_type{});
+    }
   }
   if constexpr (EPI == 1) {
     if (g.colsum_ws) {
