@@ -81,6 +81,15 @@ int sbr_gemm_wres_supported(long M, int N, int K);
 int sbr_gemm_wres_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
                       int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream);
 
+/* The same products (same arguments, same epilogues) on the bf16 matrix pipe: both fp32 operands are split exactly into three bf16
+ * numbers each (8 + 8 + 8 significand bits) and the six leading partial products are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 (csrc/gemm_split_f32.hip). The dropped terms are below 2^-23 of each product, i.e. the result carries
+ * the error of an fp32 GEMM (summation order differs from sbr_gemm_f32, so it is not bit-identical to it); the kernel is bound by
+ * HBM instead of the fp32 matrix pipe. Non-finite inputs give NaN. Replaces the same reference lines as sbr_gemm_wres_f32. */
+int sbr_gemm_split_supported(long M, int N, int K);
+int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
+                       int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream);
+
 /* HOST function (no device work): numpy's legacy `np.random.randint(0, high, size=n)` on a caller-owned MT19937 state
  * (key[624] + position from np.random.get_state(), advanced in place) — the draws of the default negative-sampling collate
  * (data/dataloader.py:154-198, np.random.choice(items_in_split, n) on the global RandomState). Bit-identical values and final

@@ -1,0 +1,290 @@
+// fp32 GEMM on the bf16 matrix pipe for the shared single-branch network's own products: C[M, 128] = A[M, 128] x W (W: 128 x 128).
+//
+// The layers of the shared MLP (algorithms/sgd_alg.py:1819-1833 -> modules/polylinear.py:51) multiply a tall activation matrix
+// (R = B * N * k rows; 90,112 at the bench's batch) by a 128 x 128 weight, forward (NT: x W^T + b, activation) and backward
+// (NN: dZ W -> dX). With v_mfma_f32_32x32x2_f32 these products are bound by the fp32 matrix pipe (157 TFLOP/s: 19 us of pipe time
+// against 15 us of HBM time, 38-42 us measured).  The bf16 pipe is 16x faster per multiply-add, and an fp32 number IS the exact
+// sum of three bf16 numbers:
+//     x = x0 + x1 + x2,   x0 = bf16_rne(x), x1 = bf16_rne(x - x0), x2 = x - x0 - x1   (8 + 8 + 8 significand bits; both
+//     subtractions are exact in fp32, and the last remainder has at most 8 significant bits, so x2 is exact)
+// so   x * w = sum_{i + j <= 2} x_i w_j  +  (x1 w2 + x2 w1 + x2 w2),   |dropped| <= 2^-23 |x w|   (|x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|)
+// i.e. six bf16 MFMAs (products exact, fp32 accumulate) give the product to within one fp32 rounding of each term: the same
+// error class as the fp32 pipe's own accumulation, at 16 / 6 = 2.7x its rate.  The kernel below is therefore bound by HBM
+// (92 MB per product), not by the matrix pipe.  tests/test_hip_kernels.py::test_split_gemm_* measures the error against an fp64
+// product next to the fp32-pipe kernel's.  Non-finite inputs give NaN (inf - inf in the split) where the fp32 pipe gives inf.
+//
+// Layout of the work (no barrier after the set-up):
+//   * one workgroup of 8 waves per CU; the weight is split ONCE per workgroup into three bf16 planes that stay in LDS (96 KB) in
+//     MFMA operand order: fragment (plane p, column tile j, k step s) is 64 lanes x 16 bytes, one ds_read_b128 per lane;
+//   * every wave owns whole 32-row blocks of A (block = global wave id + i * waves): it reads its rows straight from global memory
+//     into registers (lane = row, 32 contiguous bytes per k step), splits them with 4.5 VALU ops per element and runs
+//     4 column tiles x 8 k steps x 6 MFMAs; no operand is shared between waves, so nothing has to be synchronised;
+//   * the next half block is in flight while the current one is multiplied (two 32-register raw buffers);
+//   * epilogue options of the training step as in gemm_wres_f32.hip: bias + activation (forward); multiply by the activation
+//     derivative of a second matrix Y and accumulate column sums (backward: dZ_prev = (dZ W) * act'(Y) and its bias gradient).
+#include "gemm_args.h"
+#include <type_traits>
+
+#define SP_N 128
+#define SP_K 128
+#define SP_WAVES 8
+#define SP_PLANE (4 * 8 * 64 * 16)           // bytes of one bf16 plane of W in fragment order: [4 column tiles][8 k steps][64 lanes][8 bf16]
+
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sp_u32x4 sp_lds_u32x4;
+
+struct SplitArgs {
+  const float* A; long lda;
+  const float* W; long ldw;
+  const float* bias;
+  float* C; long ldc;
+  long M;
+  int act;
+  const float* Y; long ldy;        // EPI 1: C = (A W) * act'(Y)
+  double* colsum_ws;                // EPI 1: += column sums of C (replica layout of sbr_col_reduce, K = 1), may be null
+};
+
+__device__ __forceinline__ unsigned sp_pack(float x, float y) {     // two fp32 -> two bf16 (round to nearest even), x in the low half
+  sp_f32x2 v = {x, y};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sp_bf16x2));
+}
+
+// (x, y) -> three packed bf16 pairs with x = x0 + x1 + x2 exactly
+__device__ __forceinline__ void sp_split2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = sp_pack(x, y);
+  x -= __uint_as_float(p0 << 16);
+  y -= __uint_as_float(p0 & 0xffff0000u);
+  p1 = sp_pack(x, y);
+  x -= __uint_as_float(p1 << 16);
+  y -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = sp_pack(x, y);
+}
+
+__device__ __forceinline__ void sp_split8(const float4 lo, const float4 hi, sp_u32x4& p0, sp_u32x4& p1, sp_u32x4& p2) {
+  unsigned a, b, c;
+  sp_split2(lo.x, lo.y, a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
+  sp_split2(lo.z, lo.w, a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
+  sp_split2(hi.x, hi.y, a, b, c); p0[2] = a; p1[2] = b; p2[2] = c;
+  sp_split2(hi.z, hi.w, a, b, c); p0[3] = a; p1[3] = b; p2[3] = c;
+}
+
+__device__ __forceinline__ sp_f32x16 sp_mfma(const sp_u32x4 a, const sp_u32x4 b, const sp_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sp_bf16x8, a), __builtin_bit_cast(sp_bf16x8, b), c, 0, 0, 0);
+}
+
+// MODE 0: NT (W is [n][k]); MODE 1: NN (W is [k][n]). EPI 0: bias + activation; EPI 1: activation derivative of Y + column sums.
+template <int MODE, int EPI>
+__global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs g, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // Block -> wave: SIMD sid = 4 blockIdx + (wave & 3) of the chip takes blocks sid, sid + S, sid + 2 S, ... (S = SIMDs in the grid),
+  // alternating between its two waves, so that the matrix pipes - the shared resource of the two waves - get equal block counts
+  // (2,816 blocks over 1,024 pipes: 3 or 2 each; numbering the waves 8 blockIdx + wave would give 4 or 2).
+  const int gw = (wave >> 2) * (gridDim.x * 4) + blockIdx.x * 4 + (wave & 3), nw = gridDim.x * SP_WAVES;
+
+  // raw A of one half block: k steps 4 h .. 4 h + 3, per step the 8 floats k = 16 s + 8 half .. + 7 of row l31 of the block
+  auto load_half = [&](int blk, int h, float4 (&raw)[4][2]) {
+    long row = (long)blk * 32 + l31;
+    if (row >= g.M) row = g.M - 1;                               // rows past the end are computed on a valid row and never stored
+    const float* p = g.A + row * g.lda + h * 64 + half * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      raw[s][0] = *reinterpret_cast<const float4*>(p + s * 16);
+      raw[s][1] = *reinterpret_cast<const float4*>(p + s * 16 + 4);
+    }
+  };
+  float4 r0[4][2], r1[4][2];
+  if (gw < n_blocks) load_half(gw, 0, r0);                       // in flight during the set-up
+
+  // ---- set-up: the weight as three bf16 planes in fragment order. Chunk (n, kc) = the 8 values W(n, 8 kc .. 8 kc + 7) is the operand
+  // of lane (n & 31) + 32 (kc & 1) in fragment (column tile n >> 5, k step kc >> 1). 2048 chunks, 4 per thread.
+#pragma unroll
+  for (int i = 0; i < 2048 / (64 * SP_WAVES); ++i) {
+    const int c = t + i * 64 * SP_WAVES;
+    int n, kc;
+    float4 lo, hi;
+    if constexpr (MODE == 0) {                                   // rows of W are contiguous in k: 16 consecutive threads read one row
+      n = c >> 4; kc = c & 15;
+      const float* p = g.W + (long)n * g.ldw + kc * 8;
+      lo = *reinterpret_cast<const float4*>(p);
+      hi = *reinterpret_cast<const float4*>(p + 4);
+    } else {                                                     // rows of W are contiguous in n: consecutive threads read consecutive n
+      n = c & 127; kc = c >> 7;
+      const float* p = g.W + (long)(kc * 8) * g.ldw + n;
+      lo = make_float4(p[0], p[g.ldw], p[2 * g.ldw], p[3 * g.ldw]);
+      hi = make_float4(p[4 * g.ldw], p[5 * g.ldw], p[6 * g.ldw], p[7 * g.ldw]);
+    }
+    sp_u32x4 p0, p1, p2;
+    sp_split8(lo, hi, p0, p1, p2);
+    const int off = ((((n >> 5) * 8 + (kc >> 1)) * 64) + (kc & 1) * 32 + (n & 31)) * 16;
+    *(sp_lds_u32x4*)(smem + off) = p0;
+    *(sp_lds_u32x4*)(smem + SP_PLANE + off) = p1;
+    *(sp_lds_u32x4*)(smem + 2 * SP_PLANE + off) = p2;
+  }
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == 0) {
+    if (g.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bj[j] = g.bias[j * 32 + l31];
+    }
+  }
+  __syncthreads();                                               // the only barrier of the kernel
+
+  const unsigned char* wfrag = smem + lane * 16;
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};                           // EPI 1: running column sums of columns 32 j + l31 over this lane's rows
+
+  sp_f32x16 acc[4];
+  auto mult_half = [&](int h, const float4 (&raw)[4][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sp_u32x4 a0, a1, a2;
+      sp_split8(raw[s][0], raw[s][1], a0, a1, a2);
+      const int ks = h * 4 + s;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {                           // two column tiles at a time: two independent accumulator chains
+        sp_u32x4 w[2][3];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            w[jj][p] = *(const sp_lds_u32x4*)(wfrag + p * SP_PLANE + (((jp * 2 + jj) * 8 + ks) * 64) * 16);
+        // smallest terms first
+        acc[jp * 2 + 0] = sp_mfma(a2, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a2, w[1][0], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][2], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][2], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a1, w[0][1], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a1, w[1][1], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a1, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a1, w[1][0], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][1], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][1], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][0], acc[jp * 2 + 1]);
+      }
+    }
+  };
+
+#pragma unroll 1
+  for (int blk = gw; blk < n_blocks; blk += nw) {
+    const long m0 = (long)blk * 32;
+    load_half(blk, 1, r1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    mult_half(0, r0);
+    if (blk + nw < n_blocks) load_half(blk + nw, 0, r0);
+    mult_half(1, r1);
+
+    // ---- epilogue: accumulator register r of column tile j is row (r & 3) + 8 (r >> 2) + 4 half of the block, column 32 j + l31
+    const int rows_left = (int)(g.M - m0) - 4 * half;
+    auto finish = [&](auto kind_tag, auto full_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;            // 0: + bias, 1: relu(+ bias), 2: sbr_act(+ bias), 3: * act'(Y)
+      constexpr bool FULL = decltype(full_tag)::value;
+      float* cp = g.C + (m0 + 4 * half) * g.ldc + l31;
+      const float* yp = nullptr;
+      if constexpr (KIND == 3) yp = g.Y + (m0 + 4 * half) * g.ldy + l31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float ts = 0.f;
+        float yv[16];
+        if constexpr (KIND == 3) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2);
+            yv[r] = (FULL || lr < rows_left) ? yp[(long)lr * g.ldy + j * 32] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2);
+          float v = acc[j][r];
+          if constexpr (KIND <= 2) v += bj[j];
+          if constexpr (KIND == 1) v = v > 0.f ? v : 0.f;
+          if constexpr (KIND == 2) v = sbr_act(v, g.act);
+          if constexpr (KIND == 3) {
+            v = v * sbr_act_grad_from_out(yv[r], g.act);
+            if (FULL || lr < rows_left) ts += v;
+          }
+          if (FULL || lr < rows_left) cp[(long)lr * g.ldc + j * 32] = v;
+        }
+        if constexpr (KIND == 3) cs[j] += (double)ts;
+      }
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    const bool full = m0 + 32 <= g.M;
+    if constexpr (EPI == 1) {
+      if (full) finish(T3{}, std::true_type{}); else finish(T3{}, std::false_type{});
+    } else if (g.act == SBR_ACT_NONE) {
+      if (full) finish(T0{}, std::true_type{}); else finish(T0{}, std::false_type{});
+    } else if (g.act == SBR_ACT_RELU) {
+      if (full) finish(T1{}, std::true_type{}); else finish(T1{}, std::false_type{});
+    } else {
+      if (full) finish(T2{}, std::true_type{}); else finish(T2{}, std::false_type{});
+    }
+  }
+  if constexpr (EPI == 1) {
+    if (g.colsum_ws) {
+      // rows 4 half + ... of the two lane halves -> one sum per column and wave; one double atomic per column, wave and kernel
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double o = cs[j] + __shfl_xor(cs[j], 32, 64);
+        if (half == 0) atomicAdd(g.colsum_ws + (long)(1 + (gw % SBR_COLRED_REP)) * SP_N + j * 32 + l31, o);
+      }
+    }
+  }
+}
+
+static bool sp_al16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+// 1 when sbr_gemm_split_f32 takes this product (else use sbr_gemm_f32 / sbr_gemm_wres_f32): N = K = 128
+extern "C" int sbr_gemm_split_supported(long M, int N, int K) { return M >= 1 && N == SP_N && K == SP_K; }
+
+// mode 0 (NT): C = act(A W^T + bias), W [128 n][128 k]; mode 1 (NN): C = A W, W [128 k][128 n]. fp32 operands and result; the
+// multiplications run on the bf16 matrix pipe over exact three-way splits of both operands (six terms, fp32 accumulate).
+// Y != NULL (mode 1 only): C = (A W) * act'(Y) with `act` the activation whose OUTPUT Y is, and colsum_ws (17 * 128 doubles,
+// contract of sbr_colsum / sbr_colred_finish, may be NULL) receives the pending column sums of C.
+extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
+                                  long M, int N, int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream) {
+  SBR_REQUIRE(mode == 0 || mode == 1, "sbr_gemm_split_f32: mode %d", mode);
+  if (M == 0) return SBR_OK;
+  SBR_REQUIRE(sbr_gemm_split_supported(M, N, K), "sbr_gemm_split_f32: shape %ld x %d x %d not supported (N = K = 128)", M, N, K);
+  SBR_REQUIRE(A && W && C, "sbr_gemm_split_f32: null operand");
+  SBR_REQUIRE(sp_al16(A, lda) && (mode == 1 || sp_al16(W, ldw)), "sbr_gemm_split_f32: operands must be 16-byte aligned");
+  SBR_REQUIRE(!(Y && mode == 0) && !(colsum_ws && !Y) && !(Y && bias), "sbr_gemm_split_f32: Y / colsum_ws belong to mode 1 without bias");
+  SplitArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.act = act; g.Y = Y; g.ldy = ldy;
+  g.colsum_ws = colsum_ws;
+  const int n_blocks = sbr_cdiv(M, 32);
+  int grid = sbr_cdiv(n_blocks, SP_WAVES);
+  if (grid > 256) grid = 256;
+  const size_t lds = 3 * SP_PLANE;
+  hipStream_t s = (hipStream_t)stream;
+#define SP_LAUNCH(MODE, EPI)                                                                                              \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)gemm_split_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        sbr_set_error("sbr_gemm_split_f32: cannot raise the dynamic LDS limit");                                           \
+        return SBR_ERR_HIP;                                                                                                \
+      }                                                                                                                    \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    gemm_split_kernel<MODE, EPI><<<grid, 64 * SP_WAVES, lds, s>>>(g, n_blocks);                                            \
+  } while (0)
+  if (mode == 0) SP_LAUNCH(0, 0);
+  else if (Y) SP_LAUNCH(1, 1);
+  else SP_LAUNCH(1, 0);
+#undef SP_LAUNCH
+  SBR_CHECK_LAUNCH("sbr_gemm_split_f32");
+  return SBR_OK;
+}

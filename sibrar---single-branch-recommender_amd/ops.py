@@ -78,6 +78,17 @@ def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, 
 import os as _os
 
 _WRES = _os.environ.get('SBR_GEMM_WRES', '1') != '0'
+# fp32 products on the bf16 matrix pipe over exact three-way operand splits (csrc/gemm_split_f32.hip); '0' keeps every product on
+# the fp32 pipe (v_mfma_f32_32x32x2_f32)
+_SPLIT = _os.environ.get('SBR_GEMM_SPLIT', '1') != '0'
+_SPLIT_MIN_ROWS = 4096          # below this the per-workgroup weight set-up is not amortised
+
+
+def _mlp_kernel(M, N, K) -> str:
+    """Entry point for an N = K = 128 product without gathers (checked by ``_wres_ok``)."""
+    if _SPLIT and M >= _SPLIT_MIN_ROWS and lib().sbr_gemm_split_supported(int(M), int(N), int(K)):
+        return 'sbr_gemm_split_f32'
+    return 'sbr_gemm_wres_f32'
 
 
 def _wres_ok(M, N, K, *tensors) -> bool:
@@ -97,7 +108,7 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     if a_idx is None and c_idx is None and _wres_ok(M, N, K, x, W, out):
         _timed(('gemm_f32', 0, M, N, K, False),
-               lambda: call('sbr_gemm_wres_f32', 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+               lambda: call(_mlp_kernel(M, N, K), 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
                             act, None, 0, None, stream()))
         return out
     ws_bytes = lib().sbr_gemm_nt_splitk_workspace(M, N, K) if M > 0 else 0
@@ -120,7 +131,7 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None, out=None):
         out = torch.empty(M, N, device=dz.device, dtype=torch.float32)
     if a_idx is None and _wres_ok(M, N, K, dz, W, out):
         _timed(('gemm_f32', 1, M, N, K, False),
-               lambda: call('sbr_gemm_wres_f32', 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, 0,
+               lambda: call(_mlp_kernel(M, N, K), 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, 0,
                             None, 0, None, stream()))
         return out
     gemm(1, dz, dz.stride(0), a_idx, W, W.stride(0), None, None, out, out.stride(0), None, M, N, K, 0, 0)
@@ -138,7 +149,7 @@ def matmul_nn_actgrad(dz, W, y, act: int, out, colsum_ws=None):
     M = dz.shape[0]
     K, N = W.shape
     _timed(('gemm_f32', 1, M, N, K, False),
-           lambda: call('sbr_gemm_wres_f32', 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, act,
+           lambda: call(_mlp_kernel(M, N, K), 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, act,
                         ptr(y), y.stride(0), ptr(colsum_ws), stream()))
     return out
 

@@ -633,6 +633,7 @@ def test_weights_resident_gemm_is_bit_identical_to_the_ring_kernel(M, monkeypatc
     every activation the step uses, NN — including a ragged last tile; and its fused backward epilogue (activation derivative of a
     second matrix + the column sums of the result) == NN product -> sbr_act_grad_gather -> sbr_colsum."""
     ops = S().ops
+    monkeypatch.setattr(ops, '_SPLIT', False)
     x, w, b = _rand(M, 128, seed=41).to(DEV), (_rand(128, 128, seed=42) / 8).to(DEV), _rand(128, seed=43).to(DEV)
     y_act = torch.relu(_rand(M, 128, seed=44)).to(DEV)
     res = {}
@@ -655,3 +656,49 @@ def test_weights_resident_gemm_is_bit_identical_to_the_ring_kernel(M, monkeypatc
     assert torch.equal(out, unf)
     close(db.cpu(), ops.colsum(unf).cpu(), rtol=1e-5, atol=1e-5, what='folded bias gradient', norm_rtol=1e-6)
     assert float(ws.abs().max()) == 0.0                       # the finishing launch left the workspace zeroed
+
+
+@pytest.mark.parametrize('M', [1, 31, 32, 200, 4097, 90112])
+def test_split_gemm_has_the_error_of_the_fp32_pipe(M, monkeypatch):
+    """sbr_gemm_split_f32 (fp32 operands split exactly into three bf16 numbers each, six bf16 MFMA terms, fp32 accumulate) against an
+    fp64 product: its error is of the size of the fp32-pipe kernel's own (summation order differs, so not bit-identical), for NT with
+    bias + activations, NN, a ragged last block, and the fused backward epilogue with its folded bias gradient. Operands span six
+    decades so that all three split planes carry weight."""
+    ops = S().ops
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    g = torch.Generator().manual_seed(77)
+    scale = torch.pow(10., torch.randint(-3, 3, (M, 128), generator=g).float())
+    x = (_rand(M, 128, seed=41) * scale).to(DEV)
+    w, b = (_rand(128, 128, seed=42) / 8).to(DEV), _rand(128, seed=43).to(DEV)
+    y_act = torch.relu(_rand(M, 128, seed=44)).to(DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, '_SPLIT', flag)
+        res[flag] = [ops.linear_nt(x, w, b, act) for act in (0, 1, 2)] + [ops.matmul_nn(x, w)]
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    pre = xd @ wd.t() + bd
+    absum = xd.abs() @ wd.abs().t() + bd.abs()                 # the scale rounding errors are relative to
+    refs = [pre, torch.relu(pre), None, xd @ wd]
+    for i in (0, 1, 3):
+        mag = absum if i < 3 else xd.abs() @ wd.abs()
+        e_split = ((res[True][i].double().cpu() - refs[i]).abs() / mag).max().item()
+        e_f32 = ((res[False][i].double().cpu() - refs[i]).abs() / mag).max().item()
+        assert e_split <= max(2.0 * e_f32, 2.0 ** -22), (i, e_split, e_f32)
+        rms_split = ((res[True][i].double().cpu() - refs[i]) / mag).pow(2).mean().sqrt().item()
+        rms_f32 = ((res[False][i].double().cpu() - refs[i]) / mag).pow(2).mean().sqrt().item()
+        assert rms_split <= max(2.0 * rms_f32, 2.0 ** -24), (i, rms_split, rms_f32)
+    # tanh epilogue: 1-Lipschitz in the pre-activation, whose two versions are each within 2^-22 * absum of the fp64 value
+    assert bool(((res[True][2].double().cpu() - res[False][2].double().cpu()).abs() <= 2.0 ** -20 * absum + 1e-6).all())
+    # fused epilogue
+    monkeypatch.setattr(ops, '_SPLIT', True)
+    out = torch.empty(M, 128, device=DEV)
+    ws = ops.new_colsum_ws(x.device, 128)
+    ops.matmul_nn_actgrad(x, w, y_act, 1, out, ws)
+    db = torch.empty(128, device=DEV)
+    ops.colred_finish([(ws, db)])
+    want = (xd @ wd) * (y_act.double().cpu() > 0)
+    mag = xd.abs() @ wd.abs()
+    assert (((out.double().cpu() - want).abs()) / mag).max().item() <= 2.0 ** -20
+    assert torch.equal(out == 0, (y_act <= 0) | (out == 0))
+    close(db.cpu(), out.double().sum(0).cpu(), rtol=1e-5, atol=1e-5, what='folded bias gradient', norm_rtol=1e-6)
+    assert float(ws.abs().max()) == 0.0

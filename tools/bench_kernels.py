@@ -36,9 +36,17 @@ def gemm_suite():
         ('TN dW    128x128 over 90112', 2 * 90112 * 128 * 128, lambda: ops.matmul_tn(dZ, H)),
         ('TN dWproj 128x768 over 45056 gather', 2 * 45056 * 128 * 768, lambda: ops.matmul_tn(dZt, X, b_idx=rows, n_rows=45056)),
     ]
+    outb = torch.empty(90112, 128, device=dev)
     for name, flops, fn in cases:
         ms = timeit(fn)
         print(f'{name:42s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.2f} TFLOP/s')
+    for split in (True, False):
+        ops._SPLIT = split
+        tag = 'bf16x3 split' if split else 'fp32 pipe   '
+        for name, fn in [('NT mlp', lambda: ops.linear_nt(H, W2, None, 1, out=outb)), ('NN dx', lambda: ops.matmul_nn(dZ, W2, out=outb)),
+                         ('NN dx*act\'(Y)', lambda: ops.matmul_nn_actgrad(dZ, W2, H, 1, outb, None))]:
+            ms = timeit(fn)
+            print(f'{tag} {name:18s} 90112x128x128 {ms*1e3:9.1f} us  {2*90112*128*128/ms/1e9:8.2f} TFLOP/s  {2*90112*512/ms/1e6:7.1f} GB/s')
 
 
 def score_suite():
