@@ -18,26 +18,13 @@
 // SELECTION of the k best (st_select: bitwise binary search of the k-th key over ballot counts), in the final pass by ranking
 // (st_compact: counting over LDS broadcasts, sorted output) — which raises the row's threshold. Rows are owned by exactly one
 // wave: the top-k state needs no cross-wave synchronisation. This kernel serves D = 256; D <= 128 takes the wide kernel below.
-#include "common.h"
-#include <hip/hip_fp16.h>
-#include <stdlib.h>
+#include "score_topk_common.h"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) int lds_int;
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
 #define ST_WAVES 7                       // consumer waves
 #define ST_ROWS (ST_WAVES * 32)          // users per workgroup
 #define ST_THREADS ((ST_WAVES + 1) * 64) // + loader wave
 
-__device__ __forceinline__ unsigned int st_f2key(float f) {
-  const unsigned int u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float st_key2f(unsigned int k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
 
 struct TopkState {
   lds_u64* buf;              // [rows][cap] composite keys (score key << 32 | ~item); explicit LDS address space: 32-bit
@@ -45,9 +32,6 @@ struct TopkState {
   int cap, k;
 };
 
-// Lanes of one wave exchange candidate entries through LDS without any hardware synchronisation (LDS operations of a wave
-// execute in order); the wavefront-scope fence only stops the compiler from caching / forwarding values across the exchange.
-__device__ __forceinline__ void st_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // all 64 lanes of the owning wave: keep the k best of the first n (wave-uniform) entries of row r's buffer, sorted;
 // returns the new threshold (-inf while fewer than k entries exist)
@@ -150,17 +134,6 @@ __device__ __noinline__ RowState st_overflow(TopkState st, float v, bool pending
   return out;
 }
 
-template <int N>
-__device__ __forceinline__ void st_wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// wave-uniform read of an LDS word that another wave of the workgroup writes
-__device__ __forceinline__ int st_peek(lds_int* p) {
-  st_wave_fence();
-  const int v = *(volatile lds_int*)p;
-  return __builtin_amdgcn_readfirstlane(v);
-}
 
 template <int KS, int NS, int ST_TILE, int DBG>   // KS = D / 16; NS = LDS ring slots; ST_TILE = items per LDS tile (32 | 64); DBG: ablations
 __global__ __launch_bounds__(ST_THREADS, 2) void score_topk_f16_kernel(
@@ -853,50 +826,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void score_topk_f16_wide_kernel(
 #define S4_WAVES 7
 #define S4_ROWS (S4_WAVES * 64)
 #define S4_THREADS ((S4_WAVES + 1) * 64)
-#define S4_CAPH 64                       // candidate buffer entries per (user, lane half) in the global workspace
 
-// All 64 lanes of the owning wave: the k best of the n0 + n1 (each <= 64, wave-uniform) entries of a user's two buffer halves
-// (lane l holds b0[l] and b1[l]) are stored to b0[0 .. k), unsorted; returns the k-th best score (-inf and nothing moved while
-// fewer than k entries exist). e / keep: the lane's two entries and whether they survived.
-__device__ __forceinline__ float s4_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane,
-                                           unsigned long long e[2], bool keep[2]) {
-  const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
-  // written and read by this wave only: same-CU vector memory path, in order (see s3_select)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  e[0] = lane < n0 ? b0[lane] : 0ull;
-  e[1] = lane < n1 ? b1[lane] : 0ull;
-  keep[0] = lane < n0;
-  keep[1] = lane < n1;
-  if (n0 + n1 < k) return -INFINITY;
-  const unsigned int h0 = (unsigned int)(e[0] >> 32), h1 = (unsigned int)(e[1] >> 32);
-  unsigned int T = 0u;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned int trial = T | (1u << bit);
-    const int cnt = __popcll(__ballot(h0 >= trial)) + __popcll(__ballot(h1 >= trial));
-    T = cnt >= k ? trial : T;
-  }
-  unsigned long long C = (unsigned long long)T << 32;
-  const int c_ge = __popcll(__ballot(h0 >= T)) + __popcll(__ballot(h1 >= T));
-  if (c_ge != k) {
-    const int need = k - (__popcll(__ballot(h0 > T)) + __popcll(__ballot(h1 > T)));
-    const unsigned int l0 = (unsigned int)e[0], l1 = (unsigned int)e[1];
-    unsigned int Lw = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned int trial = Lw | (1u << bit);
-      const int cnt = __popcll(__ballot(h0 == T && l0 >= trial)) + __popcll(__ballot(h1 == T && l1 >= trial));
-      Lw = cnt >= need ? trial : Lw;
-    }
-    C |= (unsigned long long)Lw;
-  }
-  keep[0] = e[0] >= C;
-  keep[1] = e[1] >= C;
-  const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
-  const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m0, 0u));
-  const int p1 = __popcll(m0) + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m1, 0u));
-  if (keep[0]) b0[p0] = e[0];
-  if (keep[1]) b0[p1] = e[1];
-  return st_key2f(T);
-}
 
 template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations; PRE: prefix pass compiled in
 __global__ __launch_bounds__(S4_THREADS, 2) void score_topk_f16_t_kernel(
@@ -1354,7 +1284,9 @@ static bool st_use_wide(int D) {
 extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) {
   (void)I; (void)k;
   const long wgs = sbr_cdiv(Bu, S3_ROWS);
-  return wgs * S3_ROWS * (long)S3_CAP * 8 + wgs * S3_WAVES * 64L;
+  const long older = wgs * S3_ROWS * (long)S3_CAP * 8 + wgs * S3_WAVES * 64L;
+  const long narrow = s5_workspace_bytes(Bu);
+  return older > narrow ? older : narrow;
 }
 
 template <int KS, int NS, int ST_TILE>
@@ -1387,6 +1319,10 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE(U_f16 && I_f16 && out_val && out_idx, "sbr_score_topk_f16: null operand");
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   hipStream_t s = (hipStream_t)stream;
+  // default: the narrow-wave kernel (score_topk_f16_n.hip); SBR_SCORER_V3=1 keeps the transposed 64-users-per-wave kernel and
+  // the older ones behind it for A/B timing
+  if ((D == 64 || D == 128 || D == 256) && !(getenv("SBR_SCORER_V3") && atoi(getenv("SBR_SCORER_V3")) != 0))
+    return s5_dispatch(U_f16, I_f16, D, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
   // D <= 128: the 64-users-per-wave kernel (SBR_SCORER_V1=1 keeps the first kernel for A/B timing). D = 256 stays on the first
   // kernel: two A fragment sets need 128 VGPRs; the wide kernel with 32-item tiles (<16, 6, 1>) spills A fragments to scratch
   // and reloads them inside the MFMA loop — measured 3.90 / 4.28 ms against 3.72 / 3.79 ms on 100k x 25k x 256.
