@@ -25,10 +25,23 @@
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-#define S5_MAXW 15                       // consumer waves per workgroup (+ 1 loader wave = 1024 threads)
+#ifndef S5_NL
+#define S5_NL 2                          // loader waves per workgroup
+#endif
+#define S5_MAXW (16 - S5_NL)             // consumer waves per workgroup (+ the loader waves = 1024 threads)
+#ifndef S5_PF1
+#define S5_PF1 3                         // prefetch distance (K steps of 16) with one accumulator tile per LDS tile (D = 256)
+#endif
+#ifndef S5_PF2
+#define S5_PF2 1                         // ... with two (D = 64, 128)
+#endif
+#ifndef S5_NS
+#define S5_NS 6                          // LDS ring slots of 16 KB (D = 128: 64-item tiles, D = 256: 32-item tiles)
+#endif
 #define S5_CAPH 64                       // candidate entries per (user, lane half)
 
-// All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves are stored to b0[0 .. k) (raw, unsorted);
+// All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves are stored back (raw, unsorted), k - k / 2 to
+// b0 and k / 2 to b1 (both halves keep room: a compaction is due when ONE half passes the limit);
 // returns the k-th best score (-inf, nothing moved, while fewer than k entries exist). e: the lane's two entries as composite
 // keys (ordered score key << 32 | ~item), keep: whether they survived.
 __device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane,
@@ -67,8 +80,9 @@ __device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long
   const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
   const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m0, 0u));
   const int p1 = __popcll(m0) + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m1, 0u));
-  if (keep[0]) b0[p0] = r0;
-  if (keep[1]) b0[p1] = r1;
+  const int kh = k - (k >> 1);                               // survivors 0 .. kh - 1 stay in half 0, the rest go to half 1
+  if (keep[0]) (p0 < kh ? b0 + p0 : b1 + (p0 - kh))[0] = r0;
+  if (keep[1]) (p1 < kh ? b0 + p1 : b1 + (p1 - kh))[0] = r1;
   return st_key2f(T);
 }
 
@@ -83,6 +97,12 @@ __device__ __forceinline__ void s5_append(unsigned long long* block, int pos, u3
 // fragments); device-only helpers: the host pass of hipcc rejects 64-byte "v" operands and then silently drops the kernel's stub
 __device__ __forceinline__ void s5_lds_done(const f32x16& a, const f32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(a), "v"(b) : "memory"); }
 __device__ __forceinline__ void s5_pin(const f32x16& a, const f32x16& b) { asm volatile("" ::"v"(a), "v"(b)); }
+// no-return LDS atomics as bare instructions: hipcc puts s_waitcnt vmcnt(0) in front of every LDS atomic of a wave that also
+// issues LDS-DMA (it cannot tell the DMA destination from the atomic's word), i.e. a wait for all candidate stores in flight,
+// once per tile. LDS operations of a wave execute in order; callers place the waits they need themselves.
+__device__ __forceinline__ void s5_lds_add(lds_int* p, int v) { asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned int)(size_t)p), "v"(v) : "memory"); }
+__device__ __forceinline__ void s5_lds_or(lds_int* p, unsigned int v) { asm volatile("ds_or_b32 %0, %1" ::"v"((unsigned int)(size_t)p), "v"(v) : "memory"); }
+__device__ __forceinline__ void s5_pin8(const f16x8& a) { asm volatile("" ::"v"(a)); }
 
 template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations; PRE: prefix pass compiled in
 __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
@@ -92,13 +112,15 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
   constexpr int ST_TILE = 32 * NJ;
+  constexpr int PF = NJ == 1 ? S5_PF1 : S5_PF2;            // fragment prefetch distance in K steps
+  constexpr int PF_PRE = KS >= 16 ? 1 : PF;                // ... in the prefix pass (D = 256: the class maxima need the registers)
   constexpr int LIMIT = S5_CAPH - 16 * NJ;                 // a tile adds at most 16 NJ entries to a (user, half) buffer
   constexpr int ROWB = D * 2;
   constexpr int TILEB = ST_TILE * ROWB;
   constexpr int CPR = D / 8;
   constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);
   constexpr int PER_T = (ST_TILE * CPR) / 64;
-  constexpr int LFL0 = NS > 2 ? NS - 2 : 1;
+  constexpr int LFL0 = (NS - 2) / S5_NL >= 1 ? (NS - 2) / S5_NL : 1;     // tiles in flight per loader wave
   constexpr int LFL = LFL0 * PER_T <= 63 ? LFL0 : 63 / PER_T;
   static_assert(LFL >= 1 && LFL * PER_T <= 63, "vmcnt field");
   static_assert(LIMIT >= 32, "k <= 32 entries must fit below the compaction limit");
@@ -119,9 +141,14 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
   __syncthreads();                                         // the only workgroup barrier of the kernel
 
-  if (wave == W) {
-    // ---------------------------------------------- loader wave ------------------------------------------------------
-    for (int v = 0; v < n_virt; ++v) {
+  if (wave >= W) {
+    if constexpr (DBG == 5) return;                        // lab: consumers run over whatever the ring holds, no loads, no hand-off
+    // ---------------------------------------------- loader waves -----------------------------------------------------
+    // S5_NL waves take the tiles in turn (tile v belongs to loader v % S5_NL): one wave's LDS-DMA stream tops out near one
+    // 16 KB tile per 0.65 us, which is what fourteen consumer waves eat
+    const int lw = wave - W;
+    int n_mine = 0, v_last = -1;
+    for (int v = lw; v < n_virt; v += S5_NL) {
       const int slot = v % NS;
       if (v >= NS) {
         const int need = W * (v / NS);
@@ -139,16 +166,21 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
       }
-      if (v >= LFL) {
+      v_last = v;
+      if (++n_mine > LFL) {
         st_wait_vmcnt<LFL * PER_T>();
         st_wave_fence();
-        *(volatile lds_int*)(full_lds + (v - LFL) % NS) = v - LFL + 1;
+        const int vp = v - LFL * S5_NL;
+        *(volatile lds_int*)(full_lds + vp % NS) = vp + 1;
       }
     }
     st_wait_vmcnt<0>();
     st_wave_fence();
-    for (int v = (n_virt > LFL ? n_virt - LFL : 0); v < n_virt; ++v)
-      *(volatile lds_int*)(full_lds + v % NS) = v + 1;
+    if (v_last >= 0) {
+      int vp = v_last - (LFL - 1) * S5_NL;
+      if (vp < lw) vp = lw;
+      for (; vp <= v_last; vp += S5_NL) *(volatile lds_int*)(full_lds + vp % NS) = vp + 1;
+    }
     return;
   }
 
@@ -189,6 +221,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   }
   st_wave_fence();
   bool e_pending = false;
+  int peek = 0;
   // lane (u, h): threshold of user u and byte cursor into its buffer half h (thresholds of the two halves of a user are equal)
   float thr = -INFINITY;
   const int lane_base = (l31 * 2 + half) * S5_CAPH * 8;
@@ -200,24 +233,43 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // one item tile: wait, MFMAs (S^T = I x U^T), slot release, exclusion bits of the tile -> acc, have_ex
-#define S5_TILE_BODY(V)                                                                                                  \
+#define S5_TILE_BODY(V, PFV)                                                                                                 \
     const int slot = (V) % NS;                                                                                           \
     const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;                                       \
-    while (st_peek(full_lds + slot) != (V) + 1) __builtin_amdgcn_s_sleep(1);                                             \
+    /* `peek` = FULL word of this slot as read while the previous tile was in its MFMAs (stale at worst: slow poll) */     \
+    if (DBG != 5 && __builtin_amdgcn_readfirstlane(peek) != (V) + 1) {                                                   \
+      while (st_peek(full_lds + slot) != (V) + 1) __builtin_amdgcn_s_sleep(1);                                           \
+    }                                                                                                                    \
     st_wave_fence();                                                                                                     \
     if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;                                                \
-    const unsigned char* cur = smem + slot * TILEB;                                                                      \
     f32x16 acc[NJ];                                                                                                      \
+    /* fragment reads run PF steps ahead of the MFMAs that consume them (register ring of PF + 1 steps); the scheduling    \
+       barriers keep hipcc from sinking the reads back to their use (it otherwise issues read, wait, MFMA in turn and a     \
+       wave shows the LDS latency sixteen times per tile) */                                                              \
+    f16x8 bf[(PFV) + 1][NJ];                                                                                                \
+    /* fragment of K step s, tile nj: row nj * 32 + l31, 16-byte chunk (2 s + half) ^ (l31 & SWZ) = byte offset             \
+       (s << 5) ^ lxh; lxh is pinned per tile so that the KS offsets are not kept in registers (one v_xad_u32 per read) */   \
+    const unsigned char* rowp = smem + slot * TILEB + l31 * ROWB;                                                        \
+    unsigned int lxh = (unsigned int)(((l31 & SWZ) << 4) ^ (half << 4));                                                 \
+    asm volatile("" : "+v"(lxh));                                                                                        \
+    _Pragma("unroll") for (int s = 0; s < (PFV) && s < KS; ++s) {                                                           \
+      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
+        bf[s][nj] = DBG == 6 ? ufrag[(s + nj) % KS] : *reinterpret_cast<const f16x8*>(rowp + nj * 32 * ROWB + (((unsigned int)s << 5) ^ lxh)); \
+    }                                                                                                                    \
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                     \
-      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) {                                                                \
-        const int i = nj * 32 + l31;                                                                                     \
-        const int c = 2 * s + half;                                                                                      \
-        const f16x8 b = *reinterpret_cast<const f16x8*>(cur + i * ROWB + ((c ^ (i & SWZ)) << 4));                        \
-        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, ufrag[s], s == 0 ? zero16 : acc[nj], 0, 0, 0);               \
+      if (s + (PFV) < KS) {                                                                                                 \
+        _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                \
+          bf[(s + (PFV)) % ((PFV) + 1)][nj] = DBG == 6 ? ufrag[(s + nj + 1) % KS] : *reinterpret_cast<const f16x8*>(rowp + nj * 32 * ROWB + (((unsigned int)(s + (PFV)) << 5) ^ lxh)); \
       }                                                                                                                  \
+      if (s == KS / 2) peek = *(volatile lds_int*)(full_lds + ((V) + 1) % NS);                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
+        if constexpr (DBG == 7) { s5_pin8(bf[s % ((PFV) + 1)][nj]); acc[nj] = zero16; }                                       \
+        else acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s == 0 ? zero16 : acc[nj], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }                                                                                                                    \
     s5_lds_done(acc[0], acc[NJ - 1]);                                                                                    \
-    if (lane == 0) atomicAdd((int*)(free_lds + slot), 1);                                                                \
+    if (DBG != 5 && lane == 0) s5_lds_add(free_lds + slot, 1);                                                                \
     /* exclusions of this tile: item column `col` of the tile, user L: one bit for the lane that holds that accumulator —  \
        lane L + 32 ((col >> 2) & 1), bit (col >> 5) * 16 + (col & 3) + 4 ((col & 31) >> 3) */                             \
     const int gbase = item_offset + j0;                                                                                  \
@@ -231,7 +283,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       if (take) {                                                                                                        \
         const int col = e0 - gbase;                                                                                      \
         const int tgt = wave * 64 + l31 + 32 * ((col >> 2) & 1);                                                         \
-        atomicOr(&exw[tgt], 1u << ((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3)));                                \
+        s5_lds_or((lds_int*)(exw + tgt), 1u << ((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3)));                     \
         st_wave_fence();                                                                                                 \
         e0 = enx_lds[t];                                                                                                 \
         ++eidx;                                                                                                          \
@@ -250,15 +302,12 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
 
   // ---- pass 1: prefix tiles, running maximum per accumulator register (item class) ----
   if (PRE && n_pre > 0) {
-    f32x16 cm[NJ];
+    f32x16 cm;                                             // item class = (lane half, accumulator register): 32 per user
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cm[nj][r] = -INFINITY;
-    }
+    for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
     for (int v = 0; v < n_pre; ++v) {
       const int j0 = v * ST_TILE;
-      S5_TILE_BODY(v)
+      S5_TILE_BODY(v, PF_PRE)
       if (have_ex) {                                       // excluded scores must not raise a class maximum
         st_wave_fence();
         const unsigned int ex0 = exw[t];
@@ -282,12 +331,12 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         }
       }
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cm[nj][r] = fmaxf(cm[nj][r], acc[nj][r]);
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (NJ == 2) cm[r] = __builtin_fmaxf(cm[r], __builtin_fmaxf(acc[0][r], acc[1][r]));      // one v_max3
+        else cm[r] = fmaxf(cm[r], acc[0][r]);
       }
     }
-    // k-th largest of the user's 32 NJ class maxima (16 NJ in each of its two lanes): bitwise binary search on the ordered keys,
+    // k-th largest of the user's 32 class maxima (16 in each of its two lanes): bitwise binary search on the ordered keys,
     // every lane pair for its own user. The threshold admits scores EQUAL to the bound (its items are not in any buffer).
     {
       unsigned int T = 0u;
@@ -295,10 +344,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         const unsigned int trial = T | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c += st_f2key(cm[nj][r]) >= trial;
-        }
+        for (int r = 0; r < 16; ++r) c += st_f2key(cm[r]) >= trial;
         c += __shfl_xor(c, 32, 64);
         T = c >= k ? trial : T;
       }
@@ -336,7 +382,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         const float nt = s5_select(b0, b0 + S5_CAPH, n0, n1, k, lane, e, kp);
         if (n0 + n1 >= k && l31 == u) {
           thr = nt;
-          pos = lane_base + (half ? 0 : k * 8);
+          pos = lane_base + (half ? (k >> 1) : k - (k >> 1)) * 8;
         }
         if constexpr (DBG == 4) ++n_ins;
       }
@@ -345,10 +391,10 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     const int j0 = tl * ST_TILE;
     const int vseq = n_pre + tl;
     const unsigned long long ti0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-    S5_TILE_BODY(vseq)
+    S5_TILE_BODY(vseq, PF)
     const unsigned long long ti1 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
     if constexpr (DBG == 4) t_issue += ti1 - ti0 - (__builtin_amdgcn_s_memtime() - ti1);
-    if constexpr (DBG == 1) {
+    if constexpr (DBG == 1 || DBG >= 5) {
       s5_pin(acc[0], acc[NJ - 1]);
       continue;
     }
@@ -492,14 +538,18 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
   int n_pre = n_tiles >= 96 ? n_tiles / 12 : 0;
   if (getenv("SBR_ST_PRE")) n_pre = atoi(getenv("SBR_ST_PRE"));
   if (n_pre > n_tiles) n_pre = n_tiles;
-  if (n_pre < 0 || !PRE || k > 24 * NJ) n_pre = 0;        // the bound is the k-th of 32 NJ class maxima: needs k below that
+  if (n_pre < 0 || !PRE || k > 24) n_pre = 0;             // the bound is the k-th of 32 class maxima: needs k below that
+  // 1 | 2 | 5 | 6 | 7: timing-only ablations (1: MFMA loop only; 2: + threshold compares; of the MFMA loop 5: without loads and
+  // hand-off, 6: without fragment reads, 7: without MFMAs), 4: cycle stamps
   auto kern = dbg == 1 ? score_topk_f16_n_kernel<KS, NS, NJ, 1, PRE> : (dbg == 2 ? score_topk_f16_n_kernel<KS, NS, NJ, 2, PRE> :
-              (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>));
+              (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : (dbg == 5 ? score_topk_f16_n_kernel<KS, NS, NJ, 5, PRE> :
+              (dbg == 6 ? score_topk_f16_n_kernel<KS, NS, NJ, 6, PRE> : (dbg == 7 ? score_topk_f16_n_kernel<KS, NS, NJ, 7, PRE> :
+               score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>)))));
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  kern<<<(unsigned int)n_wg, (W + 1) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k,
+  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k,
                                                    n_pre, W, out_val, out_idx, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
   return SBR_OK;
@@ -510,8 +560,8 @@ int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long
                 int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
   switch (D) {
     case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 128: return s5_launch<8, 6, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 256: return s5_launch<16, 6, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 128: return s5_launch<8, S5_NS, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 256: return s5_launch<16, S5_NS, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported by the narrow-wave kernel", D);
       return SBR_ERR_ARG;
