@@ -317,13 +317,17 @@ int sbr_merge_topk(const float* vals, const int* idxs, int W, long Bu, int k, fl
 int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const long* label_indptr, const int* label_indices,
                      long Bu, const int* ks, int n_ks, float* out, void* stream);
 /* fused scorer: fp16 MFMA  U[Bu, D] x I[I_s, D]^T  with the exclusion mask and the running per-user top-k kept on chip; the
- * [Bu, I_s] score matrix is never written (BASELINE config 5). See csrc/score_topk_f16.hip. */
+ * [Bu, I_s] score matrix is never written (BASELINE config 5). D in {64, 128, 256}, k <= 32. Output sorted by (score desc, item
+ * index asc); indices are global (item_offset + column). u_idx: exclusion-CSR row of every scored row (NULL: identity).
+ * excl_nnz: number of entries of `excl_indices` (an upper bound of the exclusions of the scored rows; sizes the event stream the
+ * call builds from the CSR rows, see csrc/score_topk_f16_n.hip). ABI 2: excl_nnz is new. */
 int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
-                       const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val, int* out_idx,
-                       void* workspace, long workspace_bytes, void* stream);
-/* bytes of `workspace` for the call above: per-user candidate buffers of the 64-users-per-wave kernel (D = 64 | 128; L2-resident
- * scratch touched only by the wave that owns the user; contents need no initialisation). */
-long sbr_score_topk_f16_workspace(long Bu, int I, int k);
+                       const long* excl_indptr, const int* excl_indices, long excl_nnz, int item_offset, int k, float* out_val,
+                       int* out_idx, void* workspace, long workspace_bytes, void* stream);
+/* bytes of `workspace` for the call above: per-user candidate buffers (1 KB per user, L2-resident scratch touched only by the wave
+ * that owns the user; contents need no initialisation) + the exclusion event stream of the call (4 bytes per CSR entry + per-user
+ * bookkeeping; excl_nnz = 0 when no exclusion CSR is passed). */
+long sbr_score_topk_f16_workspace(long Bu, int I, int k, long excl_nnz);
 /* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
 int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);
 

@@ -79,6 +79,6 @@ __device__ __forceinline__ float s4_select(unsigned long long* b0, unsigned long
 }
 
 // narrow-wave kernel (score_topk_f16_n.hip)
-long s5_workspace_bytes(long Bu);
-int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+long s5_workspace_bytes(long Bu, long excl_nnz);
+int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
                 int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s);

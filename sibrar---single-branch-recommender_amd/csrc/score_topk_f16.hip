@@ -1281,11 +1281,11 @@ static bool st_use_wide(int D) {
 
 // bytes of the candidate-buffer workspace (wide kernel: S3_CAP entries per user, users padded to whole workgroups; + the
 // cycle stamps of SBR_ST_DEBUG=4). D = 0: the largest over all D.
-extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) {
+extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k, long excl_nnz) {
   (void)I; (void)k;
   const long wgs = sbr_cdiv(Bu, S3_ROWS);
   const long older = wgs * S3_ROWS * (long)S3_CAP * 8 + wgs * S3_WAVES * 64L;
-  const long narrow = s5_workspace_bytes(Bu);
+  const long narrow = s5_workspace_bytes(Bu, excl_nnz);
   return older > narrow ? older : narrow;
 }
 
@@ -1311,7 +1311,7 @@ static int st_launch(const void* U, const void* It, long Bu, int I, const long* 
 }
 
 extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
-                                  const long* excl_indptr, const int* excl_indices, int item_offset, int k, float* out_val,
+                                  const long* excl_indptr, const int* excl_indices, long excl_nnz, int item_offset, int k, float* out_val,
                                   int* out_idx, void* workspace, long workspace_bytes, void* stream) {
   SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
   SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
@@ -1322,7 +1322,7 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   // default: the narrow-wave kernel (score_topk_f16_n.hip); SBR_SCORER_V3=1 keeps the transposed 64-users-per-wave kernel and
   // the older ones behind it for A/B timing
   if ((D == 64 || D == 128 || D == 256) && !(getenv("SBR_SCORER_V3") && atoi(getenv("SBR_SCORER_V3")) != 0))
-    return s5_dispatch(U_f16, I_f16, D, Bu, I, u_idx, excl_indptr, excl_indices, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    return s5_dispatch(U_f16, I_f16, D, Bu, I, u_idx, excl_indptr, excl_indices, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
   // D <= 128: the 64-users-per-wave kernel (SBR_SCORER_V1=1 keeps the first kernel for A/B timing). D = 256 stays on the first
   // kernel: two A fragment sets need 128 VGPRs; the wide kernel with 32-item tiles (<16, 6, 1>) spills A fragments to scratch
   // and reloads them inside the MFMA loop — measured 3.90 / 4.28 ms against 3.72 / 3.79 ms on 100k x 25k x 256.

@@ -35,9 +35,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef S5_PF2
 #define S5_PF2 1                         // ... with two (D = 64, 128)
 #endif
+#ifndef S5_PRIO
+#define S5_PRIO 0                        // s_setprio level of a consumer wave while it issues a tile's MFMAs (0: none)
+#endif
 #ifndef S5_NS
 #define S5_NS 6                          // LDS ring slots of 16 KB (D = 128: 64-item tiles, D = 256: 32-item tiles)
 #endif
+#define S5_EV_NONE 0xFFFFFFFFu            // padding event: its tile field matches no tile
 #define S5_CAPH 64                       // candidate entries per (user, lane half)
 
 // All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves are stored back (raw, unsorted), k - k / 2 to
@@ -101,13 +105,60 @@ __device__ __forceinline__ void s5_pin(const f32x16& a, const f32x16& b) { asm v
 // issues LDS-DMA (it cannot tell the DMA destination from the atomic's word), i.e. a wait for all candidate stores in flight,
 // once per tile. LDS operations of a wave execute in order; callers place the waits they need themselves.
 __device__ __forceinline__ void s5_lds_add(lds_int* p, int v) { asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned int)(size_t)p), "v"(v) : "memory"); }
+// the same from lane 0 only, all lanes active on entry and exit: an EXEC flip around the instruction instead of a divergent block
+__device__ __forceinline__ void s5_lds_add_lane0(lds_int* p, int v) {
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"((unsigned int)(size_t)p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void s5_lds_or(lds_int* p, unsigned int v) { asm volatile("ds_or_b32 %0, %1" ::"v"((unsigned int)(size_t)p), "v"(v) : "memory"); }
+// maximum of four accumulator registers as v_max3 + v_max (fmaxf makes hipcc canonicalise every operand first: a v_max x, x each)
+__device__ __forceinline__ float s5_max4(float a, float b, float c, float d) {
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(d));
+  return m;
+}
+__device__ __forceinline__ float s5_max2(float a, float b) {
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
+// Branch-free append of one accumulator value: lanes with a > thr whose exclusion bit is clear store the raw entry
+// (~item = il - C, score bits) at their byte cursor and advance it. The vector ALU writes EXEC itself (v_cmpx), so the
+// sequence has no vector -> scalar hand-over and no branch; all lanes are active on entry and on exit. rs: buffer descriptor of
+// the wave's candidate block (s5_block_rsrc).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <unsigned int BIT, int C>
+__device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs) {
+  unsigned int tmp;
+  asm volatile(
+      "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
+      "v_and_b32_e32 %[tmp], %[bit], %[ex]\n\t"
+      "v_cmpx_eq_u32_e32 0, %[tmp]\n\t"
+      "v_subrev_u32_e32 %[tmp], %[c], %[il]\n\t"
+      "buffer_store_dword %[tmp], %[pos], %[rs], 0 offen\n\t"
+      "buffer_store_dword %[a], %[pos], %[rs], 0 offen offset:4\n\t"
+      "v_add_u32_e32 %[pos], 8, %[pos]\n\t"
+      "s_mov_b64 exec, -1"
+      : [pos] "+v"(pos), [tmp] "=&v"(tmp)
+      : [a] "v"(a), [thr] "v"(thr), [ex] "v"(ex), [il] "v"(il), [rs] "s"(rs), [bit] "n"(BIT), [c] "n"(C)
+      : "vcc", "memory");
+}
+// raw buffer descriptor of a wave's candidate block: base, stride 0, 32 users x 2 halves x S5_CAPH entries of 8 bytes, gfx950 format word
+__device__ __forceinline__ i32x4 s5_block_rsrc(const void* block) {
+  const unsigned long long b = (unsigned long long)block;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)(b >> 32) & 0xFFFF);
+  r[2] = 32 * 2 * S5_CAPH * 8;
+  r[3] = 0x00020000;
+  return r;
+}
 __device__ __forceinline__ void s5_pin8(const f16x8& a) { asm volatile("" ::"v"(a)); }
 
 template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations; PRE: prefix pass compiled in
 __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
-    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const long* __restrict__ u_idx,
-    const long* __restrict__ excl_indptr, const int* __restrict__ excl_indices, int item_offset, int k, int n_pre, int W,
+    const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const unsigned int* __restrict__ events,
+    const int* __restrict__ group_base, int item_offset, int k, int n_pre, int W,
     float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ gbuf,
     unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
@@ -125,11 +176,8 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   static_assert(LFL >= 1 && LFL * PER_T <= 63, "vmcnt field");
   static_assert(LIMIT >= 32, "k <= 32 entries must fit below the compaction limit");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned int* exw = reinterpret_cast<unsigned int*>(smem + NS * TILEB);                            // [S5_MAXW * 64]
-  int* enx = reinterpret_cast<int*>(exw + S5_MAXW * 64);                                             // [S5_MAXW * 64]
-  lds_int* full_lds = (lds_int*)(enx + S5_MAXW * 64);
+  lds_int* full_lds = (lds_int*)(smem + NS * TILEB);
   lds_int* free_lds = full_lds + NS;
-  lds_int* enx_lds = (lds_int*)enx;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -195,38 +243,34 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
   }
   unsigned long long* wgb = gbuf + (row0 + (long)wave * 32) * (2 * S5_CAPH);      // wave-uniform: buffers of the wave's 32 users
-  exw[t] = 0u;
-  // exclusion cursor: lane L < 32 walks the sorted CSR row of user 32 * wave + L in step with the item tiles; e0 = next excluded
-  // item, the one after it sits in LDS. lo0: restart point of the main pass.
-  const long my_row = row0 + wave * 32 + l31;
-  long eidx = 0, eend = 0, lo0 = 0;
-  int e0 = 0x7FFFFFFF;
-  {
-    int e1 = 0x7FFFFFFF;
-    if (half == 0 && my_row < Bu && excl_indptr) {
-      const long u = u_idx ? u_idx[my_row] : my_row;
-      long lo = excl_indptr[u];
-      eend = excl_indptr[u + 1];
-      long hi = eend;
-      while (lo < hi) {
-        const long mid = (lo + hi) >> 1;
-        if (excl_indices[mid] < item_offset) lo = mid + 1; else hi = mid;
-      }
-      lo0 = lo;
-      if (lo < eend) e0 = excl_indices[lo];
-      if (lo + 1 < eend) e1 = excl_indices[lo + 1];
-      eidx = lo + 1;
-    }
-    enx[t] = e1;
+  const i32x4 wrs = s5_block_rsrc(wgb);
+  // Exclusions arrive as a wave-uniform EVENT stream (s5_build_events): for this wave's 32 users, one 32-bit word per excluded
+  // (user, item) of the scored item range, ordered by item tile: tile << 11 | lane that holds the accumulator << 5 | its bit.
+  // The wave reads it with scalar loads, a quad at a time and one quad ahead (w: current, shifted down as events are consumed;
+  // n: next), and applies an event with one v_cmp / v_cndmask / v_or. Scalar loads do not share a counter with the candidate
+  // stores (a per-lane walk of the CSR rows has to wait on vmcnt, i.e. for every store in flight), and a user with thousands of
+  // exclusions costs its events, not a serialised round per entry for the whole wave.
+  // (a wave past the last user group — padding of the last workgroup — has no group_base entry: it runs without events)
+  const bool has_excl = events != nullptr && (row0 >> 5) + wave < ((Bu + 31) >> 5);      // wave-uniform
+  const unsigned int* evp = nullptr;
+  unsigned int w0 = S5_EV_NONE, w1 = S5_EV_NONE, w2 = S5_EV_NONE, w3 = S5_EV_NONE, n0 = S5_EV_NONE, n1 = S5_EV_NONE, n2 = S5_EV_NONE, n3 = S5_EV_NONE;
+  int ev_rem = 4, ev_q = 8;
+#define S5_EV_RESTART()                                                                                                  \
+  if (has_excl) {                                                                                                        \
+    const uint4 qa = *reinterpret_cast<const uint4*>(evp), qb = *reinterpret_cast<const uint4*>(evp + 4);                \
+    w0 = qa.x; w1 = qa.y; w2 = qa.z; w3 = qa.w; n0 = qb.x; n1 = qb.y; n2 = qb.z; n3 = qb.w;                             \
+    ev_rem = 4; ev_q = 8;                                                                                                \
   }
-  st_wave_fence();
-  bool e_pending = false;
+  if (has_excl) evp = events + group_base[(row0 >> 5) + wave];
+  S5_EV_RESTART()
   int peek = 0;
+  int slot_next = 0;                                       // ring slot of the next tile of the sequence
   // lane (u, h): threshold of user u and byte cursor into its buffer half h (thresholds of the two halves of a user are equal)
   float thr = -INFINITY;
   const int lane_base = (l31 * 2 + half) * S5_CAPH * 8;
   int pos = lane_base;
 
+  unsigned long long t_mid = 0;
   unsigned long long t_wait = 0, t_evt = 0, n_evt = 0, n_ins = 0, n_cand = 0, t_cmp = 0, t_issue = 0, t_ladder = 0;
   const unsigned long long t_begin = DBG != 0 ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt_begin = DBG != 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -234,7 +278,8 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
 
   // one item tile: wait, MFMAs (S^T = I x U^T), slot release, exclusion bits of the tile -> acc, have_ex
 #define S5_TILE_BODY(V, PFV)                                                                                                 \
-    const int slot = (V) % NS;                                                                                           \
+    const int slot = slot_next;                            /* = (V) % NS, kept as a wrapping counter */                    \
+    slot_next = slot + 1 == NS ? 0 : slot + 1;                                                                           \
     const unsigned long long tw0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;                                       \
     /* `peek` = FULL word of this slot as read while the previous tile was in its MFMAs (stale at worst: slow poll) */     \
     if (DBG != 5 && __builtin_amdgcn_readfirstlane(peek) != (V) + 1) {                                                   \
@@ -256,49 +301,41 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
         bf[s][nj] = DBG == 6 ? ufrag[(s + nj) % KS] : *reinterpret_cast<const f16x8*>(rowp + nj * 32 * ROWB + (((unsigned int)s << 5) ^ lxh)); \
     }                                                                                                                    \
+    if constexpr (S5_PRIO != 0) __builtin_amdgcn_s_setprio(S5_PRIO);   /* MFMA phase wins the SIMD's issue arbitration */    \
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                     \
       if (s + (PFV) < KS) {                                                                                                 \
         _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                \
           bf[(s + (PFV)) % ((PFV) + 1)][nj] = DBG == 6 ? ufrag[(s + nj + 1) % KS] : *reinterpret_cast<const f16x8*>(rowp + nj * 32 * ROWB + (((unsigned int)(s + (PFV)) << 5) ^ lxh)); \
       }                                                                                                                  \
-      if (s == KS / 2) peek = *(volatile lds_int*)(full_lds + ((V) + 1) % NS);                                           \
+      if (s == KS / 2) peek = *(volatile lds_int*)(full_lds + slot_next);                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
       _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
         if constexpr (DBG == 7) { s5_pin8(bf[s % ((PFV) + 1)][nj]); acc[nj] = zero16; }                                       \
         else acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s == 0 ? zero16 : acc[nj], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }                                                                                                                    \
+    if constexpr (S5_PRIO != 0) __builtin_amdgcn_s_setprio(0);                                                           \
     s5_lds_done(acc[0], acc[NJ - 1]);                                                                                    \
-    if (DBG != 5 && lane == 0) s5_lds_add(free_lds + slot, 1);                                                                \
-    /* exclusions of this tile: item column `col` of the tile, user L: one bit for the lane that holds that accumulator —  \
-       lane L + 32 ((col >> 2) & 1), bit (col >> 5) * 16 + (col & 3) + 4 ((col & 31) >> 3) */                             \
-    const int gbase = item_offset + j0;                                                                                  \
-    bool wrote_ex = false;                                                                                               \
-    for (int round = 0;; ++round) {                                                                                      \
-      const bool take = e0 < gbase + ST_TILE;                                                                            \
-      if (!__ballot(take)) break;                                                                                        \
-      if (e_pending) st_wait_vmcnt<0>();                                                                                 \
-      e_pending = false;                                                                                                 \
-      wrote_ex = true;                                                                                                   \
-      if (take) {                                                                                                        \
-        const int col = e0 - gbase;                                                                                      \
-        const int tgt = wave * 64 + l31 + 32 * ((col >> 2) & 1);                                                         \
-        s5_lds_or((lds_int*)(exw + tgt), 1u << ((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3)));                     \
-        st_wave_fence();                                                                                                 \
-        e0 = enx_lds[t];                                                                                                 \
-        ++eidx;                                                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-        if (eidx < eend) {                                                                                               \
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(excl_indices + eidx),         \
-                                           (__attribute__((address_space(3))) void*)(enx + wave * 64), 4, 0, 0);         \
-        } else {                                                                                                         \
-          enx_lds[t] = 0x7FFFFFFF;                                                                                       \
-          st_wave_fence();                                                                                               \
+    if constexpr (DBG == 3) t_mid = __builtin_amdgcn_s_memtime();                                                        \
+    if constexpr (DBG != 5) s5_lds_add_lane0(free_lds + slot, 1);                                                        \
+    /* exclusion events of this tile -> one bit per excluded score in the lane that holds it */                          \
+    unsigned int ex = 0u;                                                                                                \
+    bool have_ex = false;                                                                                                \
+    if (has_excl) {                                                                                                      \
+      const unsigned int tkey = (unsigned int)(j0 / ST_TILE);                                                            \
+      while ((w0 >> 11) == tkey) {                                                                                       \
+        ex |= lane == (int)((w0 >> 5) & 63u) ? 1u << (w0 & 31u) : 0u;                                                    \
+        have_ex = true;                                                                                                  \
+        w0 = w1; w1 = w2; w2 = w3;                                                                                       \
+        if (--ev_rem == 0) {                                                                                             \
+          w0 = n0; w1 = n1; w2 = n2; w3 = n3;                                                                            \
+          const uint4 qn = *reinterpret_cast<const uint4*>(evp + ev_q);                                                  \
+          n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w;                                                                    \
+          ev_rem = 4; ev_q += 4;                                                                                         \
         }                                                                                                                \
       }                                                                                                                  \
-      e_pending = true;                                                                                                  \
-    }                                                                                                                    \
-    const bool have_ex = __ballot(wrote_ex) != 0ull;
+    }
+
 
   // ---- pass 1: prefix tiles, running maximum per accumulator register (item class) ----
   if (PRE && n_pre > 0) {
@@ -309,15 +346,12 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       const int j0 = v * ST_TILE;
       S5_TILE_BODY(v, PF_PRE)
       if (have_ex) {                                       // excluded scores must not raise a class maximum
-        st_wave_fence();
-        const unsigned int ex0 = exw[t];
+        const unsigned int ex0 = ex;
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[nj][r] = ((ex0 >> (nj * 16 + r)) & 1u) ? -INFINITY : acc[nj][r];
         }
-        exw[t] = 0u;
-        st_wave_fence();
       }
       if (j0 + ST_TILE > I) {                              // catalogue end inside the tile: padded columns do not count
         const int lim = I - j0 - 4 * half;
@@ -351,16 +385,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       // T = 0x007FFFFF is the key of -inf (fewer than k finite classes): no bound
       thr = T > 0x007FFFFFu ? st_key2f(T - 1u) : -INFINITY;
     }
-    // restart the exclusion cursor for the main pass
-    if (excl_indptr) st_wait_vmcnt<0>();
-    e_pending = false;
-    e0 = 0x7FFFFFFF;
-    int e1 = 0x7FFFFFFF;
-    if (lo0 < eend) e0 = excl_indices[lo0];
-    if (lo0 + 1 < eend) e1 = excl_indices[lo0 + 1];
-    eidx = lo0 + 1;
-    enx_lds[t] = e1;
-    st_wave_fence();
+    S5_EV_RESTART()                                        // the main pass starts again from the first tile
   }
 
   // ---- pass 2: all tiles, lane-local threshold filter and appends ----
@@ -390,16 +415,15 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     }
     const int j0 = tl * ST_TILE;
     const int vseq = n_pre + tl;
-    const unsigned long long ti0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ti0 = (DBG == 4 || DBG == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
     S5_TILE_BODY(vseq, PF)
+    if constexpr (DBG == 3) t_issue += t_mid - ti0;
     const unsigned long long ti1 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
     if constexpr (DBG == 4) t_issue += ti1 - ti0 - (__builtin_amdgcn_s_memtime() - ti1);
     if constexpr (DBG == 1 || DBG >= 5) {
       s5_pin(acc[0], acc[NJ - 1]);
       continue;
     }
-    unsigned int ex = 0u;
-    if (have_ex) { st_wave_fence(); ex = exw[t]; }
     if (j0 + ST_TILE > I) {                                // catalogue end inside the (last) tile: padded columns never qualify
       const int lim = I - j0 - 4 * half;                   // item (r & 3) + 8 (r >> 2) + 32 nj of this lane exists iff < lim
 #pragma unroll
@@ -412,42 +436,38 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       }
     }
     const unsigned int item_lane = 0xFFFFFFFFu - (unsigned int)(item_offset + j0 + 4 * half);
+    // Threshold ladder. A wave is in-order and a vector -> scalar hand-over (v_cmp -> s_cbranch, v_cmp -> s_and_saveexec) costs
+    // ~25 cycles every time, so the ladder does ALL its vector work first — the maximum of every PAIR of accumulator registers
+    // and one v_cmp per pair into its own SGPR pair, back to back — then dispatches on scalar registers only (one branch for
+    // "nothing in this tile", s_cmp + branch per pair), and a pair that fired runs a branch-free append per register in which
+    // the vector ALU writes EXEC itself (s5_try_append). Measured with one wave per SIMD, per tile: 1,550 cycles when every
+    // group and every register paid hand-overs of its own, ~? after.
+    unsigned long long gm[8 * NJ];
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // common path per FOUR accumulator registers: four v_cmp into SGPR pairs issued back to back, three s_or, one scalar
-        // branch (a v_cmp -> branch pair per register serialises on the compare's latency)
-        unsigned long long bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = __ballot(acc[nj][4 * g + q] > thr);
-        if constexpr (DBG == 2) { if (bq[0] | bq[1] | bq[2] | bq[3]) asm volatile("s_nop 0"); continue; }
-        if (bq[0] | bq[1] | bq[2] | bq[3]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int r = 4 * g + q;
-            if (bq[q]) {
-              const unsigned long long te0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
-              // everything below hangs off values pinned inside the branch (hipcc otherwise if-converts the block and
-              // evaluates exclusion arithmetic for every register of every tile)
-              float v = acc[nj][r];
-              unsigned int exv = ex;
-              asm volatile("" : "+v"(v), "+v"(exv));
-              const int C = nj * 32 + (r & 3) + 8 * (r >> 2);          // compile-time after unrolling
-              const bool cand = (v > thr) && !((exv >> (nj * 16 + r)) & 1u);
-              if (cand) {
-                const u32x2 ent = {item_lane - (unsigned int)C, __float_as_uint(v)};
-                s5_append(wgb, pos, ent);
-                pos += 8;
-              }
-              if constexpr (DBG == 4) { n_cand += __popcll(__ballot(cand)); t_evt += __builtin_amdgcn_s_memtime() - te0; ++n_evt; }
-            }
-          }
-        }
-      }
+      for (int g = 0; g < 8; ++g) gm[nj * 8 + g] = __ballot(s5_max2(acc[nj][2 * g], acc[nj][2 * g + 1]) > thr);
     }
-    if (have_ex) { exw[t] = 0u; st_wave_fence(); }
+    unsigned long long any_g = 0ull;
+#pragma unroll
+    for (int i = 0; i < 8 * NJ; ++i) any_g |= gm[i];
+    if constexpr (DBG == 2) { if (any_g) asm volatile("s_nop 0"); continue; }
+    if (any_g) {
+      // item of register r: nj * 32 + (r & 3) + 8 * (r >> 2) (+ 4 * half, in item_lane); exclusion bit nj * 16 + r
+#define S5_PAIR(NJI, G)                                                                                                  \
+      if (gm[(NJI) * 8 + (G)]) {                                                                                         \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G))), (NJI) * 32 + ((2 * (G)) & 3) + 8 * ((2 * (G)) >> 2)>(acc[NJI][2 * (G)], thr, ex, pos, item_lane, wrs);             \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G) + 1)), (NJI) * 32 + ((2 * (G) + 1) & 3) + 8 * ((2 * (G) + 1) >> 2)>(acc[NJI][2 * (G) + 1], thr, ex, pos, item_lane, wrs); \
+        if constexpr (DBG == 4) ++n_evt;                                                                                 \
+      }
+      S5_PAIR(0, 0) S5_PAIR(0, 1) S5_PAIR(0, 2) S5_PAIR(0, 3) S5_PAIR(0, 4) S5_PAIR(0, 5) S5_PAIR(0, 6) S5_PAIR(0, 7)
+      if constexpr (NJ == 2) {
+        S5_PAIR(NJ - 1, 0) S5_PAIR(NJ - 1, 1) S5_PAIR(NJ - 1, 2) S5_PAIR(NJ - 1, 3) S5_PAIR(NJ - 1, 4) S5_PAIR(NJ - 1, 5) S5_PAIR(NJ - 1, 6) S5_PAIR(NJ - 1, 7)
+      }
+#undef S5_PAIR
+    }
     if constexpr (DBG == 4) t_ladder += __builtin_amdgcn_s_memtime() - ti1;
+    if constexpr (DBG == 3) t_ladder += __builtin_amdgcn_s_memtime() - t_mid;
   }
 #undef S5_TILE_BODY
 
@@ -495,6 +515,108 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Exclusion events (see the consumer prologue of the kernel): built per call from the exclusion CSR by three small kernels.
+//   rows:    one thread per scored user row: the part of its sorted CSR row that falls into [item_offset, item_offset + I)
+//            (two binary searches), counted into its 32-user group
+//   scan:    one workgroup: group g gets room for its events rounded up to a quad + two quads of padding (the consumer reads
+//            one quad ahead), exclusive prefix sum -> group_base
+//   scatter: one workgroup per group: counting sort of the group's events by item tile in LDS (histogram, prefix sum,
+//            scatter); events of one tile stay in arbitrary order (their bits are OR-ed); padding words are S5_EV_NONE
+// event = tile << 11 | (u + 32 ((col >> 2) & 1)) << 5 | ((col >> 5) * 16 + (col & 3) + 4 ((col & 31) >> 3)):
+// col = item column inside the tile, u = user inside the group — the lane and the accumulator bit of that score.
+__global__ void s5_ev_rows_kernel(long Bu, const long* __restrict__ u_idx, const long* __restrict__ indptr, const int* __restrict__ indices,
+                                  int item_offset, int I, long* __restrict__ row_lo, int* __restrict__ row_cnt, int* __restrict__ grp_cnt) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Bu) return;
+  const long u = u_idx ? u_idx[r] : r;
+  const long b = indptr[u], e = indptr[u + 1];
+  long lo = b, hi = e;
+  while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < item_offset) lo = mid + 1; else hi = mid; }
+  const long first = lo;
+  const long lim = (long)item_offset + I;
+  hi = e;
+  while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < lim) lo = mid + 1; else hi = mid; }
+  row_lo[r] = first;
+  row_cnt[r] = (int)(lo - first);
+  if (lo > first) atomicAdd(grp_cnt + (r >> 5), (int)(lo - first));
+}
+
+__global__ __launch_bounds__(1024) void s5_ev_scan_kernel(int G, const int* __restrict__ grp_cnt, int* __restrict__ group_base) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (G + 1023) / 1024;
+  const int g0 = t * per, g1 = g0 + per < G ? g0 + per : G;
+  int sum = 0;
+  for (int g = g0; g < g1; ++g) sum += ((grp_cnt[g] + 3) & ~3) + 8;
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;                                   // exclusive prefix of this thread's chunk
+  for (int g = g0; g < g1; ++g) { group_base[g] = run; run += ((grp_cnt[g] + 3) & ~3) + 8; }
+  if (t == 1023) group_base[G] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void s5_ev_scatter_kernel(long Bu, const int* __restrict__ indices, int item_offset, int tile_items, int n_tiles,
+                                                            const long* __restrict__ row_lo, const int* __restrict__ row_cnt,
+                                                            const int* __restrict__ grp_cnt, const int* __restrict__ group_base,
+                                                            unsigned int* __restrict__ events, long cap) {
+  extern __shared__ int hist[];                              // [n_tiles] counts, then running positions
+  __shared__ int part[256];
+  const int g = blockIdx.x, t = threadIdx.x;
+  const int cnt = grp_cnt[g];
+  const long base = group_base[g];
+  const int alloc = ((cnt + 3) & ~3) + 8;
+  if (base + alloc > cap) return;                            // cannot happen with a workspace of the documented size
+  if (cnt > 0) {
+    for (int i = t; i < n_tiles; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int u = 0; u < 32; ++u) {
+      const long r = (long)g * 32 + u;
+      if (r >= Bu) break;
+      const long lo = row_lo[r];
+      const int n = row_cnt[r];
+      for (int i = t; i < n; i += 256) atomicAdd(hist + (indices[lo + i] - item_offset) / tile_items, 1);
+    }
+    __syncthreads();
+    // exclusive prefix sum over the tiles: contiguous chunk per thread
+    const int per = (n_tiles + 255) / 256;
+    const int i0 = t * per, i1 = i0 + per < n_tiles ? i0 + per : n_tiles;
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += hist[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int v = t >= d ? part[t - d] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = i0; i < i1; ++i) { const int c = hist[i]; hist[i] = run; run += c; }
+    __syncthreads();
+    for (int u = 0; u < 32; ++u) {
+      const long r = (long)g * 32 + u;
+      if (r >= Bu) break;
+      const long lo = row_lo[r];
+      const int n = row_cnt[r];
+      for (int i = t; i < n; i += 256) {
+        const int rel = indices[lo + i] - item_offset;
+        const int tile = rel / tile_items, col = rel - tile * tile_items;
+        const unsigned int tgt = (unsigned int)(u + 32 * ((col >> 2) & 1));
+        const unsigned int bit = (unsigned int)((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3));
+        events[base + atomicAdd(hist + tile, 1)] = ((unsigned int)tile << 11) | (tgt << 5) | bit;
+      }
+    }
+  }
+  for (int i = cnt + t; i < alloc; i += 256) events[base + i] = S5_EV_NONE;
+}
+
 // consumer waves per workgroup: users are dealt in 32-user units over the CUs; the smallest W that keeps the number of rounds
 // (workgroups per CU, one resident at a time) at its minimum
 static int s5_pick_waves(long Bu) {
@@ -515,23 +637,66 @@ static int s5_pick_waves(long Bu) {
   return (int)(w < 1 ? 1 : (w > S5_MAXW ? S5_MAXW : w));
 }
 
-long s5_workspace_bytes(long Bu) {
-  // users padded to whole workgroups of any wave count (< 32 * S5_MAXW extra) + the cycle stamps of SBR_ST_DEBUG
+// exclusion-event region of the workspace (16-byte aligned pieces): group_base int[G + 1], grp_cnt int[G], row_cnt int[Bu],
+// row_lo long[Bu], events uint[excl_nnz + 11 G] (per group: its events rounded up to a quad + two padding quads)
+static long s5_al16(long b) { return (b + 15) & ~15L; }
+static long s5_event_bytes(long Bu, long excl_nnz) {
+  if (excl_nnz <= 0) return 0;
+  const long G = sbr_cdiv(Bu, 32);
+  return s5_al16((G + 1) * 4) + s5_al16(G * 4) + s5_al16(Bu * 4) + s5_al16(Bu * 8) + s5_al16((excl_nnz + 11 * G) * 4) + 16;
+}
+
+long s5_workspace_bytes(long Bu, long excl_nnz) {
+  // users padded to whole workgroups of any wave count (< 32 * S5_MAXW extra) + the cycle stamps of SBR_ST_DEBUG + the events
   const long padded = Bu + 32L * S5_MAXW;
-  return padded * 2 * S5_CAPH * 8 + (sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L;
+  return padded * 2 * S5_CAPH * 8 + (sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L + s5_event_bytes(Bu, excl_nnz);
 }
 
 template <int KS, int NS, int NJ, bool PRE>
-static int s5_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+static int s5_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
                      int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
   const int W = s5_pick_waves(Bu);
   const long n_wg = sbr_cdiv(Bu, 32L * W);
   const long need = n_wg * 32L * W * 2 * S5_CAPH * 8;
   const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations, 4: cycle stamps
-  SBR_REQUIRE(workspace && workspace_bytes >= need + (dbg != 0 ? n_wg * S5_MAXW * 64L : 0L),
-              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", need, workspace_bytes);
+  const long dbg_bytes = s5_al16(n_wg * S5_MAXW * 64L);
+  const bool with_excl = eptr != nullptr && excl_nnz > 0;
+  SBR_REQUIRE(workspace && workspace_bytes >= need + dbg_bytes + s5_event_bytes(Bu, with_excl ? excl_nnz : 0),
+              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given",
+              need + dbg_bytes + s5_event_bytes(Bu, with_excl ? excl_nnz : 0), workspace_bytes);
   void* dbg_buf = (char*)workspace + need;
-  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + S5_MAXW * 64 * 8 + 2 * NS * 4 + 16;
+  const unsigned int* events = nullptr;
+  const int* group_base = nullptr;
+  if (with_excl) {
+    // event stream of this call (three launches in front of the scorer on the same stream)
+    const long G = sbr_cdiv(Bu, 32);
+    const int n_tiles_ev = sbr_cdiv(I, 32 * NJ);
+    SBR_REQUIRE((long)n_tiles_ev * 4 <= 150 * 1024 && n_tiles_ev < (1 << 21) - 1,
+                "sbr_score_topk_f16: %d item tiles exceed the event builder's LDS histogram (score the catalogue in item shards)", n_tiles_ev);
+    char* p = (char*)s5_al16((long)((char*)workspace + need + dbg_bytes));
+    int* gb = (int*)p; p += s5_al16((G + 1) * 4);
+    int* gc = (int*)p; p += s5_al16(G * 4);
+    int* rc = (int*)p; p += s5_al16(Bu * 4);
+    long* rl = (long*)p; p += s5_al16(Bu * 8);
+    unsigned int* ev = (unsigned int*)p;
+    const long cap = excl_nnz + 11 * G;
+    if (hipMemsetAsync(gc, 0, G * 4, s) != hipSuccess) { sbr_set_error("sbr_score_topk_f16: memset failed"); return SBR_ERR_HIP; }
+    s5_ev_rows_kernel<<<(unsigned int)sbr_cdiv(Bu, 256), 256, 0, s>>>(Bu, u_idx, eptr, eidx, item_offset, I, rl, rc, gc);
+    s5_ev_scan_kernel<<<1, 1024, 0, s>>>((int)G, gc, gb);
+    static bool lds_raised = false;
+    if (!lds_raised) {
+      if (hipFuncSetAttribute((const void*)s5_ev_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit of the event builder");
+        return SBR_ERR_HIP;
+      }
+      lds_raised = true;
+    }
+    s5_ev_scatter_kernel<<<(unsigned int)G, 256, (size_t)n_tiles_ev * 4, s>>>(Bu, eidx, item_offset, 32 * NJ, n_tiles_ev, rl, rc, gc, gb, ev, cap);
+    SBR_CHECK_LAUNCH("sbr_score_topk_f16 (exclusion events)");
+    events = ev;
+    group_base = gb;
+  }
+  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + 2 * NS * 4 + 16;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
   // prefix pass: ~1/12 of the catalogue (whole tiles), skipped for catalogues too short to repay it; SBR_ST_PRE overrides (tiles)
   const int n_tiles = sbr_cdiv(I, 32 * NJ);
@@ -542,26 +707,26 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
   // 1 | 2 | 5 | 6 | 7: timing-only ablations (1: MFMA loop only; 2: + threshold compares; of the MFMA loop 5: without loads and
   // hand-off, 6: without fragment reads, 7: without MFMAs), 4: cycle stamps
   auto kern = dbg == 1 ? score_topk_f16_n_kernel<KS, NS, NJ, 1, PRE> : (dbg == 2 ? score_topk_f16_n_kernel<KS, NS, NJ, 2, PRE> :
-              (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : (dbg == 5 ? score_topk_f16_n_kernel<KS, NS, NJ, 5, PRE> :
+              (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : (dbg == 3 ? score_topk_f16_n_kernel<KS, NS, NJ, 3, PRE> : (dbg == 5 ? score_topk_f16_n_kernel<KS, NS, NJ, 5, PRE> :
               (dbg == 6 ? score_topk_f16_n_kernel<KS, NS, NJ, 6, PRE> : (dbg == 7 ? score_topk_f16_n_kernel<KS, NS, NJ, 7, PRE> :
-               score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>)))));
+               score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>))))));
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, u_idx, eptr, eidx, item_offset, k,
+  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, events, group_base, item_offset, k,
                                                    n_pre, W, out_val, out_idx, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
   return SBR_OK;
 }
 
 // D in {64, 128, 256}; called by sbr_score_topk_f16 (score_topk_f16.hip)
-int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx,
+int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
                 int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
   switch (D) {
-    case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 128: return s5_launch<8, S5_NS, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 256: return s5_launch<16, S5_NS, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 128: return s5_launch<8, S5_NS, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 256: return s5_launch<16, S5_NS, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported by the narrow-wave kernel", D);
       return SBR_ERR_ARG;

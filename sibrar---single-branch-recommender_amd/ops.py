@@ -677,9 +677,10 @@ def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, exc
     I = i16.shape[0]
     val = torch.empty(Bu, k, device=u16.device, dtype=torch.float32)
     idx = torch.empty(Bu, k, device=u16.device, dtype=torch.int32)
-    ws = torch.empty(max(int(lib().sbr_score_topk_f16_workspace(Bu, I, k)), 8), device=u16.device, dtype=torch.uint8)
+    nnz = 0 if excl_indices is None else int(excl_indices.numel())
+    ws = torch.empty(max(int(lib().sbr_score_topk_f16_workspace(Bu, I, k, nnz)), 8), device=u16.device, dtype=torch.uint8)
     _timed(('score_topk_f16', Bu, I, D, k),
-           lambda: call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices),
+           lambda: call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), nnz,
                         item_offset, k, ptr(val), ptr(idx), ptr(ws), ws.numel(), stream()))
     return val, idx
 

@@ -17,13 +17,13 @@ K = 20
 g = torch.Generator(device='cuda').manual_seed(1)
 u = (torch.randn(Bu, D, device='cuda', generator=g) / 8).half()
 it = (torch.randn(I, D, device='cuda', generator=g) / 8).half()
-need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K))
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K, 0))
 ws = torch.zeros(need + (1 << 20), dtype=torch.uint8, device='cuda')
 val = torch.empty(Bu, K, device='cuda'); idx = torch.empty(Bu, K, dtype=torch.int32, device='cuda')
 
 
 def launch():
-    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, K, val.data_ptr(), idx.data_ptr(),
+    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, K, val.data_ptr(), idx.data_ptr(),
            ws.data_ptr(), ws.numel(), L.stream())
 
 
@@ -84,6 +84,38 @@ if 'stamps' in what:
           f'{t_issue.mean():.3g} ({100*t_issue.mean()/tot:.1f}%) | ladder {t_ladder.mean():.3g} ({100*t_ladder.mean()/tot:.1f}%) of it candidate blocks '
           f'{d[:,2].mean():.3g} (blocks={n_evt.mean():.0f}, candidates={d[:,3].mean():.0f} = {d[:,3].mean()/32:.0f} per user) | compactions {d[:,6].mean():.3g} '
           f'({100*d[:,6].mean()/tot:.1f}%), n={n_ins.mean():.0f} = {n_ins.mean()/32:.2f} per user')
+    os.environ.pop('SBR_ST_DEBUG')
+if 'clock' in what:
+    W = pick_waves(Bu)
+    n_wg = -(-Bu // (32 * W))
+    off = n_wg * 32 * W * 2 * 64 * 8
+    for dbg, name in ((1, 'MFMA loop only'), (6, 'without fragment reads'), (5, 'without loads / hand-off'), (2, '+ compares'), (4, 'real kernel + stamps')):
+        os.environ['SBR_ST_DEBUG'] = str(dbg)
+        ws.zero_()
+        for _ in range(12): launch()
+        torch.cuda.synchronize()
+        raw = ws[off:off + n_wg * MAXW * 64].view(torch.int64).cpu().numpy().reshape(n_wg * MAXW, 8)
+        raw = raw[raw[:, 0] > 0].astype(np.float64)
+        clk = raw[:, 0] / np.maximum(raw[:, 7], 1) * 100e6 / 1e9
+        print(f'  in-kernel clock, ablation {dbg} ({name}): median {np.median(clk):.2f} GHz (p10 {np.percentile(clk,10):.2f}, p90 {np.percentile(clk,90):.2f}), '
+              f'wave wall mean {raw[:,7].mean()/100:.0f} us, cycles {raw[:,0].mean():.3g}')
+    os.environ.pop('SBR_ST_DEBUG')
+if 'phases' in what:
+    W = pick_waves(Bu)
+    n_wg = -(-Bu // (32 * W))
+    off = n_wg * 32 * W * 2 * 64 * 8
+    os.environ['SBR_ST_DEBUG'] = '3'
+    ws.zero_()
+    for _ in range(12): launch()
+    torch.cuda.synchronize()
+    raw = ws[off:off + n_wg * MAXW * 64].view(torch.int64).cpu().numpy().reshape(n_wg * MAXW, 8)
+    raw = raw[raw[:, 0] > 0]
+    t_issue, t_ladder = (raw[:, 4] >> 20).astype(np.float64), (raw[:, 5] >> 20).astype(np.float64)
+    tot = raw[:, 0].astype(np.float64)
+    nt = -(-I // (64 if D != 256 else 32))
+    print(f'  light stamps (3 per tile), per wave: total {tot.mean():.3g} cyc, wall {raw[:,7].mean()/100:.0f} us | main pass: poll + MFMA phase {t_issue.mean():.3g} '
+          f'({t_issue.mean()/nt:.0f} per tile) | release + exclusion walk + ladder + blocks {t_ladder.mean():.3g} ({t_ladder.mean()/nt:.0f} per tile) | rest '
+          f'(prefix pass, compactions, final selection) {(tot - t_issue - t_ladder).mean():.3g}')
     os.environ.pop('SBR_ST_DEBUG')
 if 'waves' in what:
     for w in (14, 13, 12, 10, 8, 7, 13, 14):

@@ -1,0 +1,77 @@
+"""Fused scorer on the bench's own model representations (c2 after a few training steps) against random data of the same shape:
+launch time with the catalogue in its own order and in a random permutation, with and without the exclusion CSR, and the
+candidates per user from the cycle stamps.   usage: python tools/scorer_on_model.py [train_steps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, numpy as np
+import bench
+import sibrar_amd as S
+from importlib import import_module
+L = import_module('sibrar---single-branch-recommender_amd._lib')
+dev = 'cuda:0'
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ds, net = bench.build(S, dict(bench.C2), dev)
+bench.bench_training(S, ds, net, dev, 8192, steps, 5, 0, 1, time_kernels=False)
+net.eval()
+K = 20
+with torch.no_grad():
+    i_repr = net.get_item_representations(torch.arange(ds.n_items, device=dev))
+    users = torch.arange(ds.n_users, device=dev)
+    u16 = S.ops.cast_f16(net.get_user_representations(users))
+    i16 = S.ops.cast_f16(i_repr.contiguous())
+    excl = S.evaluation._csr_to_device(ds.user_sampling_matrix_train, dev)
+print('user repr abs mean %.3g, item repr abs mean %.3g, item norm cv %.3g' % (float(u16.float().abs().mean()), float(i16.float().abs().mean()),
+      float(i16.float().norm(dim=1).std() / i16.float().norm(dim=1).mean())))
+Bu, I, D = u16.shape[0], i16.shape[0], u16.shape[1]
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K, int(excl[1].numel())))
+ws = torch.zeros(need + (1 << 20), dtype=torch.uint8, device=dev)
+val = torch.empty(Bu, K, device=dev); idx = torch.empty(Bu, K, dtype=torch.int32, device=dev)
+
+
+def timed(u, it, ex, warm=10, reps=20):
+    def launch():
+        L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, users.data_ptr() if ex else None, ex[0].data_ptr() if ex else None,
+               ex[1].data_ptr() if ex else None, int(ex[1].numel()) if ex else 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+    for _ in range(warm): launch()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); launch(); b.record(); evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(x.elapsed_time(y) for x, y in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def candidates(u, it):
+    os.environ['SBR_ST_DEBUG'] = '4'
+    ws.zero_()
+    for _ in range(2):
+        L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+    torch.cuda.synchronize()
+    os.environ.pop('SBR_ST_DEBUG')
+    units = -(-Bu // 32); W = max(1, min(14, -(-units // 256)))
+    n_wg = -(-Bu // (32 * W)); off = n_wg * 32 * W * 2 * 64 * 8
+    raw = ws[off:off + n_wg * 14 * 64].view(torch.int64).cpu().numpy().reshape(n_wg * 14, 8)
+    raw = raw[raw[:, 0] > 0]
+    return (raw[:, 5] & 0xFFFFF).mean() / 32, (raw[:, 4] & 0xFFFFF).mean()
+
+
+g = torch.Generator(device=dev).manual_seed(1)
+perm = torch.randperm(I, device=dev, generator=g)
+ur = (torch.randn(Bu, D, device=dev, generator=g) / 8).half(); ir = (torch.randn(I, D, device=dev, generator=g) / 8).half()
+for name, u, it in (('random data', ur, ir), ('model, catalogue order', u16, i16), ('model, items permuted', u16, i16[perm].contiguous())):
+    t0 = timed(u, it, None); t1 = timed(u, it, excl if name != 'model, items permuted' else None)
+    c = candidates(u, it)
+    print(f'{name:26s}: {t0[0]:.3f} ms (min {t0[1]:.3f}) without exclusions, {t1[0]:.3f} ms with | compactions per user {c[0]:.2f}, fired pairs per wave {c[1]:.0f}')
+
+# exclusion rows: degree distribution of the bench's train matrix and what the long tail costs
+ip = excl[0].cpu().numpy(); deg = np.diff(ip)
+print('exclusions per user: mean %.1f, median %d, p90 %d, p99 %d, max %d' % (deg.mean(), np.median(deg), np.percentile(deg, 90), np.percentile(deg, 99), deg.max()))
+ix = excl[1].cpu().numpy()
+for cap in (32, 64, 128, 256, 100000):
+    keep = np.concatenate([np.arange(ip[u], min(ip[u + 1], ip[u] + cap)) for u in range(Bu)]) if cap < 100000 else np.arange(len(ix))
+    nip = np.concatenate([[0], np.cumsum(np.minimum(deg, cap))]).astype(np.int64)
+    ex2 = (torch.from_numpy(nip).to(dev), torch.from_numpy(ix[keep].astype(np.int32)).to(dev))
+    t = timed(u16, i16, ex2)
+    print(f'  rows capped at {cap:6d} entries ({len(keep)} in all): {t[0]:.3f} ms')
