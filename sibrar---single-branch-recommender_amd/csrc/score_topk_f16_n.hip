@@ -531,12 +531,19 @@ __global__ void s5_ev_rows_kernel(long Bu, const long* __restrict__ u_idx, const
   if (r >= Bu) return;
   const long u = u_idx ? u_idx[r] : r;
   const long b = indptr[u], e = indptr[u + 1];
-  long lo = b, hi = e;
-  while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < item_offset) lo = mid + 1; else hi = mid; }
-  const long first = lo;
   const long lim = (long)item_offset + I;
-  hi = e;
-  while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < lim) lo = mid + 1; else hi = mid; }
+  // a row that lies inside the scored item range as a whole (the usual case: one shard = the whole catalogue) needs no search
+  long lo = b, hi = e;
+  if (b < e && indices[b] < item_offset) {
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < item_offset) lo = mid + 1; else hi = mid; }
+  }
+  const long first = lo;
+  if (b < e && indices[e - 1] >= lim) {
+    hi = e;
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (indices[mid] < lim) lo = mid + 1; else hi = mid; }
+  } else {
+    lo = e;
+  }
   row_lo[r] = first;
   row_cnt[r] = (int)(lo - first);
   if (lo > first) atomicAdd(grp_cnt + (r >> 5), (int)(lo - first));
@@ -574,15 +581,28 @@ __global__ __launch_bounds__(256) void s5_ev_scatter_kernel(long Bu, const int* 
   const int alloc = ((cnt + 3) & ~3) + 8;
   if (base + alloc > cap) return;                            // cannot happen with a workspace of the documented size
   if (cnt > 0) {
+    // the group's entries as ONE flat index range: rstart[u] = entries of the users before u (rows are ~50 entries long, the
+    // group ~1,600: a loop per user would leave most of the 256 threads idle)
+    __shared__ int rstart[33];
+    __shared__ long rlo[32];
+    if (t < 32) {
+      const long r = (long)g * 32 + t;
+      const int n = r < Bu ? row_cnt[r] : 0;
+      rlo[t] = r < Bu ? row_lo[r] : 0;
+      int incl = n;                                            // inclusive scan over the 32 lanes of this half wave
+      for (int d = 1; d < 32; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (t >= d) incl += v; }
+      rstart[t + 1] = incl;
+      if (t == 0) rstart[0] = 0;
+    }
     for (int i = t; i < n_tiles; i += 256) hist[i] = 0;
     __syncthreads();
-    for (int u = 0; u < 32; ++u) {
-      const long r = (long)g * 32 + u;
-      if (r >= Bu) break;
-      const long lo = row_lo[r];
-      const int n = row_cnt[r];
-      for (int i = t; i < n; i += 256) atomicAdd(hist + (indices[lo + i] - item_offset) / tile_items, 1);
-    }
+    auto entry = [&](int f, int& u) -> int {                   // flat index -> (user u, item index relative to the shard)
+      int lo_u = 0, hi_u = 31;
+      while (lo_u < hi_u) { const int mid = (lo_u + hi_u + 1) >> 1; if (rstart[mid] <= f) lo_u = mid; else hi_u = mid - 1; }
+      u = lo_u;
+      return indices[rlo[u] + (f - rstart[u])] - item_offset;
+    };
+    for (int f = t; f < cnt; f += 256) { int u; atomicAdd(hist + entry(f, u) / tile_items, 1); }
     __syncthreads();
     // exclusive prefix sum over the tiles: contiguous chunk per thread
     const int per = (n_tiles + 255) / 256;
@@ -600,18 +620,13 @@ __global__ __launch_bounds__(256) void s5_ev_scatter_kernel(long Bu, const int* 
     int run = part[t] - sum;
     for (int i = i0; i < i1; ++i) { const int c = hist[i]; hist[i] = run; run += c; }
     __syncthreads();
-    for (int u = 0; u < 32; ++u) {
-      const long r = (long)g * 32 + u;
-      if (r >= Bu) break;
-      const long lo = row_lo[r];
-      const int n = row_cnt[r];
-      for (int i = t; i < n; i += 256) {
-        const int rel = indices[lo + i] - item_offset;
-        const int tile = rel / tile_items, col = rel - tile * tile_items;
-        const unsigned int tgt = (unsigned int)(u + 32 * ((col >> 2) & 1));
-        const unsigned int bit = (unsigned int)((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3));
-        events[base + atomicAdd(hist + tile, 1)] = ((unsigned int)tile << 11) | (tgt << 5) | bit;
-      }
+    for (int f = t; f < cnt; f += 256) {
+      int u;
+      const int rel = entry(f, u);
+      const int tile = rel / tile_items, col = rel - tile * tile_items;
+      const unsigned int tgt = (unsigned int)(u + 32 * ((col >> 2) & 1));
+      const unsigned int bit = (unsigned int)((col >> 5) * 16 + (col & 3) + 4 * ((col & 31) >> 3));
+      events[base + atomicAdd(hist + tile, 1)] = ((unsigned int)tile << 11) | (tgt << 5) | bit;
     }
   }
   for (int i = cnt + t; i < alloc; i += 256) events[base + i] = S5_EV_NONE;
