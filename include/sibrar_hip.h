@@ -89,6 +89,13 @@ int sbr_gemm_wres_f32(int mode, const float* A, long lda, const float* W, long l
 int sbr_gemm_split_supported(long M, int N, int K);
 int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
                        int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream);
+/* The dense modality projector on the same arithmetic — FeatureEmbedding's nn.Linear(F, C) over gathered feature rows
+ * (algorithms/sgd_alg.py:1279-1396, forward of 1960-1974): C[ci(m), 0..127] = act(A[ai(m), 0..K-1] x W^T + bias), W [128][K],
+ * N = 128, K = 128 j >= 256; a_idx (feature row of every slot), c_idx (row of the shared network's input), bias may be NULL.
+ * The weight is walked in K chunks of 128 whose three bf16 planes are rebuilt in LDS (csrc/gemm_split_f32.hip). */
+int sbr_gemm_split_proj_supported(long M, int N, int K);
+int sbr_gemm_split_proj_f32(const float* A, long lda, const int* a_idx, const float* W, long ldw, const float* bias, float* C, long ldc,
+                            const int* c_idx, long M, int N, int K, int act, void* stream);
 
 /* HOST function (no device work): numpy's legacy `np.random.randint(0, high, size=n)` on a caller-owned MT19937 state
  * (key[624] + position from np.random.get_state(), advanced in place) — the draws of the default negative-sampling collate

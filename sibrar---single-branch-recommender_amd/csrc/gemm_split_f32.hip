@@ -288,3 +288,220 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
   SBR_CHECK_LAUNCH("sbr_gemm_split_f32");
   return SBR_OK;
 }
+
+// =====================================================================================================================
+// Modality projector on the bf16 matrix pipe: C[ci(m), 128] = act(A[ai(m), K] x W^T + bias), W [128 n][K], K a multiple of 128
+// (algorithms/sgd_alg.py:1279-1396 FeatureEmbedding of a dense modality: nn.Linear(F, C) over the gathered feature rows).
+// Same arithmetic as above (exact three-way bf16 splits of both operands, six MFMA terms, fp32 accumulate); what changes is the
+// loop: the weight does not fit in LDS as a whole (128 x 768 fp32 = three bf16 planes of 288 KB), so a workgroup walks K in
+// chunks of 128 and rebuilds the three planes of the chunk in LDS (96 KB) between two barriers, while every wave keeps the
+// accumulators of ONE 32-row block across the chunks. The row gather (a_idx: item -> feature row) is the wave's own row
+// pointer, the row scatter of the result (c_idx: slot of the shared network's input) is applied in the epilogue. The raw
+// weight values of the next chunk and the next half block of A are in flight while the current ones are multiplied.
+// With v_mfma_f32_32x32x2_f32 this product (45,824 x 128 x 768 at the bench's batch) is bound by the fp32 matrix pipe: 57 us of
+// pipe time, 96 us measured; here it needs 6 x 1/16 of that and reads 141 MB of feature rows.
+#ifndef PJ_ABL
+#define PJ_ABL 0                         // lab: 1 no MFMAs, 2 planes written once, 3 one A half block only, 4 = 2 + 3
+#endif
+struct ProjArgs {
+  const float* A; long lda; const int* a_idx;
+  const float* W; long ldw;
+  const float* bias;
+  float* C; long ldc; const int* c_idx;
+  long M;
+  int K;
+  int act;
+};
+
+#define PJ_KC 64                              // K chunk: its three bf16 planes are [4 column tiles][4 k steps][64 lanes][16 B] = 16 KB each
+#define PJ_BUF (3 * 4 * 4 * 64 * 16)          // one plane set (48 KB); two of them alternate
+
+__global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjArgs g, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int gw = (wave >> 2) * (gridDim.x * 4) + blockIdx.x * 4 + (wave & 3), nw = gridDim.x * SP_WAVES;
+  const int n_it = (n_blocks + nw - 1) / nw;
+  const int KC = g.K / PJ_KC;
+  constexpr int PL = 4 * 4 * 64 * 16;                            // bytes of one plane of a chunk
+
+  // raw weight values of one chunk. A wave-instruction handles ONE operand fragment (column tile j, k step ks): lane L reads the
+  // 8 values W(32 j + (L & 31), 16 ks + 8 (L >> 5) .. + 7) and, after the split, writes its 16 bytes at lane position L of the
+  // fragment — consecutive lanes, consecutive LDS addresses (thread order along k makes 16 lanes write 512 bytes apart: a 16-way
+  // bank conflict on every ds_write_b128). Wave w takes fragments 2 w, 2 w + 1 of the chunk's 16.
+  float4 wraw[2][2];
+  auto load_w = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = wave * 2 + i;
+      const float* p = g.W + (long)((f >> 2) * 32 + l31) * g.ldw + (long)kc * PJ_KC + (f & 3) * 16 + half * 8;
+      wraw[i][0] = *reinterpret_cast<const float4*>(p);
+      wraw[i][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = wave * 2 + i;
+      sp_u32x4 p0, p1, p2;
+      sp_split8(wraw[i][0], wraw[i][1], p0, p1, p2);
+      const int off = buf * PJ_BUF + (f * 64 + lane) * 16;
+      *(sp_lds_u32x4*)(smem + off) = p0;
+      *(sp_lds_u32x4*)(smem + PL + off) = p1;
+      *(sp_lds_u32x4*)(smem + 2 * PL + off) = p2;
+    }
+  };
+  // chunk q of a row: the 64 values k = 64 q .. 64 q + 63, per k step the 8 floats 16 s + 8 half .. + 7
+  auto load_chunk = [&](const float* arow, int q, float4 (&raw)[4][2]) __attribute__((always_inline)) {
+    const float* p = arow + q * PJ_KC + half * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      raw[s][0] = *reinterpret_cast<const float4*>(p + s * 16);
+      raw[s][1] = *reinterpret_cast<const float4*>(p + s * 16 + 4);
+    }
+  };
+  auto row_ptr = [&](int blk) -> const float* {
+    long m = (long)blk * 32 + l31;
+    if (m >= g.M) m = g.M - 1;                                   // rows past the end are computed on a valid row and never stored
+    const long r = g.a_idx ? (long)g.a_idx[m] : m;
+    return g.A + r * g.lda;
+  };
+
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bj[j] = g.bias[j * 32 + l31];
+  }
+  sp_f32x16 acc[4];
+  float4 r0[4][2], r1[4][2], r2[4][2];                           // three chunks of A rotate: two are in flight while one is multiplied
+  auto mult_chunk = [&](int buf, const float4 (&raw)[4][2]) __attribute__((always_inline)) {
+    const unsigned char* wfrag = smem + buf * PJ_BUF + lane * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sp_u32x4 a0, a1, a2;
+      sp_split8(raw[s][0], raw[s][1], a0, a1, a2);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        sp_u32x4 w[2][3];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            w[jj][p] = *(const sp_lds_u32x4*)(wfrag + p * PL + (((jp * 2 + jj) * 4 + s) * 64) * 16);
+        acc[jp * 2 + 0] = sp_mfma(a2, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a2, w[1][0], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][2], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][2], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a1, w[0][1], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a1, w[1][1], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a1, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a1, w[1][0], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][1], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][1], acc[jp * 2 + 1]);
+        acc[jp * 2 + 0] = sp_mfma(a0, w[0][0], acc[jp * 2 + 0]);
+        acc[jp * 2 + 1] = sp_mfma(a0, w[1][0], acc[jp * 2 + 1]);
+      }
+    }
+  };
+
+  // Sequence of (row block, chunk) steps of this workgroup: step c = it * KC + kc uses plane set c & 1 and raw buffer c % 3.
+  // While step c is multiplied the planes of step c + 1 are split and written into the other set (no MFMA waits for them: the
+  // matrix pipe drains the queued MFMAs meanwhile), the raw weight values of step c + 2 and the A chunk of step c + 2 (of this
+  // block or of the wave's next one) are loaded; ONE barrier per step publishes the planes of step c + 1 and retires the reads of
+  // set c & 1 before it is written again two steps later.
+  const int n_steps = n_it * KC;
+  const float* ap0 = nullptr;                                    // row pointers of the wave's blocks with even / odd `it`
+  const float* ap1 = nullptr;
+  load_w(0);
+  if (gw < n_blocks) { ap0 = row_ptr(gw); load_chunk(ap0, 0, r0); load_chunk(ap0, 1, r1); }
+  store_w(0);
+  if (n_steps > 1) load_w(1 % KC);
+  __syncthreads();
+
+#define PJ_STEP(CC, cur, fill) do { \
+    const int c = (CC); \
+    if (c >= n_steps) break; \
+    const int it = c / KC, kc = c - it * KC; \
+    const int blk = gw + it * nw; \
+    const bool valid = blk < n_blocks; \
+    if (kc == 0) { \
+_Pragma("unroll") \
+      for (int j = 0; j < 4; ++j) \
+_Pragma("unroll") \
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f; \
+    } \
+    if (valid) { \
+ \
+      const int c2 = c + 2, it2 = c2 / KC, kc2 = c2 - it2 * KC; \
+      const int blk2 = gw + it2 * nw; \
+      if (c2 < n_steps && blk2 < n_blocks) { \
+        if (kc2 == 0) { if (it2 & 1) ap1 = row_ptr(blk2); else ap0 = row_ptr(blk2); } \
+        load_chunk((it2 & 1) ? ap1 : ap0, kc2, fill); \
+      } \
+      mult_chunk(c & 1, cur); \
+    } \
+    if (c + 1 < n_steps) { \
+      store_w((c + 1) & 1); \
+      if (c + 2 < n_steps) load_w((kc + 2) % KC); \
+    } \
+    if (valid && kc == KC - 1) { \
+ \
+      const long m0 = (long)blk * 32; \
+      const int rows_left = (int)(g.M - m0) - 4 * half; \
+      long orow[16]; \
+_Pragma("unroll") \
+      for (int r = 0; r < 16; ++r) { \
+        const int lr = (r & 3) + 8 * (r >> 2); \
+        const long m = m0 + 4 * half + lr; \
+        orow[r] = (g.c_idx && lr < rows_left) ? (long)g.c_idx[m] : m; \
+      } \
+_Pragma("unroll") \
+      for (int j = 0; j < 4; ++j) { \
+_Pragma("unroll") \
+        for (int r = 0; r < 16; ++r) { \
+          const int lr = (r & 3) + 8 * (r >> 2); \
+          float v = acc[j][r] + bj[j]; \
+          v = g.act == SBR_ACT_NONE ? v : (g.act == SBR_ACT_RELU ? (v > 0.f ? v : 0.f) : sbr_act(v, g.act)); \
+          if (lr < rows_left) g.C[orow[r] * g.ldc + j * 32 + l31] = v; \
+        } \
+      } \
+    } \
+    __syncthreads(); \
+  } while (0)
+#pragma unroll 1
+  for (int c0 = 0; c0 < n_steps; c0 += 3) {
+    PJ_STEP(c0, r0, r2);
+    PJ_STEP(c0 + 1, r1, r0);
+    PJ_STEP(c0 + 2, r2, r1);
+  }
+}
+
+// 1 when sbr_gemm_split_proj_f32 takes this product: N = 128, K a multiple of 64 of at least 256
+extern "C" int sbr_gemm_split_proj_supported(long M, int N, int K) { return M >= 1 && N == SP_N && K >= 2 * SP_K && K % PJ_KC == 0; }
+
+// C[ci(m), 0..127] = act(A[ai(m), 0..K-1] x W^T + bias): A rows and W rows 16-byte aligned; a_idx / c_idx / bias may be NULL.
+extern "C" int sbr_gemm_split_proj_f32(const float* A, long lda, const int* a_idx, const float* W, long ldw, const float* bias, float* C,
+                                       long ldc, const int* c_idx, long M, int N, int K, int act, void* stream) {
+  if (M == 0) return SBR_OK;
+  SBR_REQUIRE(sbr_gemm_split_proj_supported(M, N, K), "sbr_gemm_split_proj_f32: shape %ld x %d x %d not supported (N = 128, K = 64 j >= 256)", M, N, K);
+  SBR_REQUIRE(A && W && C, "sbr_gemm_split_proj_f32: null operand");
+  SBR_REQUIRE(sp_al16(A, lda) && sp_al16(W, ldw), "sbr_gemm_split_proj_f32: operands must be 16-byte aligned");
+  ProjArgs g;
+  g.A = A; g.lda = lda; g.a_idx = a_idx; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.c_idx = c_idx; g.M = M; g.K = K; g.act = act;
+  const int n_blocks = sbr_cdiv(M, 32);
+  int grid = sbr_cdiv(n_blocks, SP_WAVES);
+  if (grid > 256) grid = 256;
+  const size_t lds = 2 * PJ_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_split_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      sbr_set_error("sbr_gemm_split_proj_f32: cannot raise the dynamic LDS limit");
+      return SBR_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  gemm_split_proj_kernel<<<grid, 64 * SP_WAVES, lds, (hipStream_t)stream>>>(g, n_blocks);
+  SBR_CHECK_LAUNCH("sbr_gemm_split_proj_f32");
+  return SBR_OK;
+}

@@ -111,6 +111,13 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
                lambda: call(_mlp_kernel(M, N, K), 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
                             act, None, 0, None, stream()))
         return out
+    if (_SPLIT and M >= _SPLIT_MIN_ROWS and lib().sbr_gemm_split_proj_supported(int(M), int(N), int(K))
+            and all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in (x, W)) and out.stride(1) == 1):
+        # dense modality projector (N = 128, K = 768 / 1024 / 2048 ...) on the bf16 matrix pipe, gather and scatter fused
+        _timed(('gemm_f32', 0, M, N, K, a_idx is not None),
+               lambda: call('sbr_gemm_split_proj_f32', ptr(x), x.stride(0), ptr(a_idx), ptr(W), W.stride(0), ptr(bias), ptr(out),
+                            out.stride(0), ptr(c_idx), M, N, K, act, stream()))
+        return out
     ws_bytes = lib().sbr_gemm_nt_splitk_workspace(M, N, K) if M > 0 else 0
     if ws_bytes > 0:
         # few output tiles, long K (the modality projectors at small batches): K split over workgroups, deterministic reduce

@@ -702,3 +702,44 @@ def test_split_gemm_has_the_error_of_the_fp32_pipe(M, monkeypatch):
     assert torch.equal(out == 0, (y_act <= 0) | (out == 0))
     close(db.cpu(), out.double().sum(0).cpu(), rtol=1e-5, atol=1e-5, what='folded bias gradient', norm_rtol=1e-6)
     assert float(ws.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K', [(4096, 768), (5000, 256), (9001, 1024)])
+def test_split_projector_gemm_has_the_error_of_the_fp32_pipe(M, K, monkeypatch):
+    """sbr_gemm_split_proj_f32 (the dense modality projector on the bf16 matrix pipe: K walked in chunks of 128, row gather and row
+    scatter fused) against an fp64 product, next to the fp32-pipe kernel on the same call: gathered rows with repeats, scattered
+    output rows, bias + the three activation kinds, a ragged last block; operands span six decades."""
+    ops = S().ops
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    g = torch.Generator().manual_seed(5)
+    n_src = 3000
+    scale = torch.pow(10., torch.randint(-3, 3, (n_src, K), generator=g).float())
+    x = (_rand(n_src, K, seed=51) * scale).to(DEV)
+    w, b = (_rand(128, K, seed=52) / 16).to(DEV), _rand(128, seed=53).to(DEV)
+    a_idx = torch.randint(0, n_src, (M,), generator=g, dtype=torch.int32).to(DEV)
+    c_idx = torch.randperm(M + 7, generator=g)[:M].to(torch.int32).to(DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, '_SPLIT', flag)
+        outs = []
+        for act in (0, 1, 2):
+            out = torch.full((M + 7, 128), 123.0, device=DEV)
+            ops.linear_nt(x, w, b, act, a_idx=a_idx, out=out, c_idx=c_idx, n_rows=M)
+            outs.append(out)
+        outs.append(ops.linear_nt(x, w, None, 0, a_idx=a_idx))            # no bias, no scatter
+        res[flag] = outs
+    xd, wd, bd = x.double().cpu()[a_idx.cpu().long()], w.double().cpu(), b.double().cpu()
+    pre = xd @ wd.t() + bd
+    absum = xd.abs() @ wd.abs().t() + bd.abs()
+    ci = c_idx.cpu().long()
+    untouched = torch.ones(M + 7, dtype=torch.bool); untouched[ci] = False
+    for i, ref in ((0, pre), (1, torch.relu(pre)), (3, xd @ wd.t())):
+        got = {f: (res[f][i].double().cpu()[ci] if i < 3 else res[f][i].double().cpu()) for f in (True, False)}
+        mag = absum if i < 3 else xd.abs() @ wd.abs().t()
+        e_split = ((got[True] - ref).abs() / mag).max().item()
+        e_f32 = ((got[False] - ref).abs() / mag).max().item()
+        assert e_split <= max(2.0 * e_f32, 2.0 ** -21), (i, e_split, e_f32)
+        if i < 3:
+            assert bool((res[True][i].cpu()[untouched] == 123.0).all())        # rows outside c_idx are not written
+    assert bool(((res[True][2].double().cpu()[ci] - res[False][2].double().cpu()[ci]).abs() <= 2.0 ** -19 * absum + 1e-6).all())

@@ -3,6 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import sibrar_amd as S
+if os.environ.get('SBR_LAB_LIB'):
+    from importlib import import_module
+    import_module('sibrar---single-branch-recommender_amd._lib').LIB_PATH = os.path.abspath(os.environ['SBR_LAB_LIB'])
 ops = S.ops
 dev = 'cuda'
 
