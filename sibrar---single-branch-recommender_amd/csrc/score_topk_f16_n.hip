@@ -241,6 +241,11 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
 #pragma unroll
     for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
+    // Name the fragments once before the tile loops: hipcc then waits for these loads HERE. Left pending, its wait lands in front of
+    // the first MFMA inside the loop as s_waitcnt vmcnt(0) — which, on every later tile, waits for the candidate stores of the
+    // previous tile (appends are inline assembly the compiler's counter model does not see).
+#pragma unroll
+    for (int s = 0; s < KS; ++s) s5_pin8(ufrag[s]);
   }
   unsigned long long* wgb = gbuf + (row0 + (long)wave * 32) * (2 * S5_CAPH);      // wave-uniform: buffers of the wave's 32 users
   const i32x4 wrs = s5_block_rsrc(wgb);
