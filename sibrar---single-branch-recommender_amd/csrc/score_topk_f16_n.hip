@@ -60,14 +60,18 @@ __device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long
   keep[1] = lane < n1;
   if (n0 + n1 < k) return -INFINITY;
   const unsigned int h0 = (unsigned int)(e[0] >> 32), h1 = (unsigned int)(e[1] >> 32);
+  // bitwise binary search for the k-th largest score key over ballot counts. It stops as soon as EXACTLY k entries lie at or above
+  // the prefix found so far: they are the k best, and the prefix itself is a valid (slightly low) threshold — with keys spread over
+  // the fp32 range that happens after 10-14 of the 32 steps (ties across the k-th place never stop it early: the count jumps past k,
+  // and the item-index search below resolves them as before).
   unsigned int T = 0u;
+  int c_ge = n0 + n1;
   for (int bit = 31; bit >= 0; --bit) {
     const unsigned int trial = T | (1u << bit);
     const int cnt = __popcll(__ballot(h0 >= trial)) + __popcll(__ballot(h1 >= trial));
-    T = cnt >= k ? trial : T;
+    if (cnt >= k) { T = trial; c_ge = cnt; if (cnt == k) break; }
   }
   unsigned long long C = (unsigned long long)T << 32;
-  const int c_ge = __popcll(__ballot(h0 >= T)) + __popcll(__ballot(h1 >= T));
   if (c_ge != k) {                                           // several entries share the k-th key: smallest item indices stay
     const int need = k - (__popcll(__ballot(h0 > T)) + __popcll(__ballot(h1 > T)));
     const unsigned int l0 = (unsigned int)e[0], l1 = (unsigned int)e[1];
@@ -87,7 +91,10 @@ __device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long
   const int kh = k - (k >> 1);                               // survivors 0 .. kh - 1 stay in half 0, the rest go to half 1
   if (keep[0]) (p0 < kh ? b0 + p0 : b1 + (p0 - kh))[0] = r0;
   if (keep[1]) (p1 < kh ? b0 + p1 : b1 + (p1 - kh))[0] = r1;
-  return st_key2f(T);
+  // T may be a PREFIX of the k-th key (low bits clear): as a float that is a value at or below the k-th best score — a valid
+  // threshold — except that clearing into the exponent of a negative score can produce a NaN pattern: no bound then
+  const float t = st_key2f(T);
+  return t == t ? t : -INFINITY;
 }
 
 // append of one raw candidate entry at byte offset `pos` of the wave's buffer block (`block`: wave-uniform, so the descriptor is
