@@ -56,24 +56,39 @@ extern "C" int sbr_resolve_rows(const long* idx, int k, const int* slots, int n,
 // order stays ascending) and writes them; the padding tails are filled by all blocks together.
 // ---------------------------------------------------------------------------------------------------------------
 #define SBR_PART_MAX 8
-#define PART_EPT 16
+#define PART_EPT_ONE 16                   // slots per thread when ONE block covers the batch (<= 4,096 slots: one launch)
+#define PART_EPT 4                        // ... otherwise: one 32-bit load, 1,024 slots per block (16 per thread = 22 blocks at the bench's 90k slots:
+                                          // latency-bound, 15 + 6 us for the two kernels)
 #define PART_CHUNK (256 * PART_EPT)
 struct PartSeg { int n_mod; int offs[SBR_PART_MAX + 1]; };
+// the EPT modality positions lo .. lo + EPT - 1 of a thread (-1 past the end); EPT = 4: one aligned 32-bit load
+template <int EPT>
+__device__ __forceinline__ void part_load(const signed char* __restrict__ pos, long lo, long R, bool aligned, signed char (&out)[EPT]) {
+  if (EPT == 4 && aligned && lo + 4 <= R) {
+    const int w = *reinterpret_cast<const int*>(pos + lo);
+    out[0] = (signed char)(w & 0xFF); out[1] = (signed char)((w >> 8) & 0xFF); out[2] = (signed char)((w >> 16) & 0xFF); out[3] = (signed char)((w >> 24) & 0xFF);
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = (lo + e < R) ? pos[lo + e] : (signed char)-1;
+  }
+}
 
+template <int EPT>
 __global__ __launch_bounds__(256) void partition_count_kernel(const signed char* __restrict__ pos, long R, int n_mod,
                                                               int* __restrict__ hist) {
   __shared__ int h[SBR_PART_MAX];
   if (threadIdx.x < SBR_PART_MAX) h[threadIdx.x] = 0;
   __syncthreads();
-  const long lo = (long)blockIdx.x * PART_CHUNK + threadIdx.x * PART_EPT;
+  const long lo = (long)blockIdx.x * (256 * EPT) + threadIdx.x * EPT;
   int local[SBR_PART_MAX];
 #pragma unroll
   for (int m = 0; m < SBR_PART_MAX; ++m) local[m] = 0;
+  signed char mine[EPT];
+  part_load<EPT>(pos, lo, R, (((uintptr_t)pos) & 3) == 0, mine);
 #pragma unroll
-  for (int e = 0; e < PART_EPT; ++e) {
-    const int m = (lo + e < R) ? pos[lo + e] : -1;
+  for (int e = 0; e < EPT; ++e) {
 #pragma unroll
-    for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (m == q);
+    for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (mine[e] == q);
   }
 #pragma unroll
   for (int m = 0; m < SBR_PART_MAX; ++m) {
@@ -84,30 +99,32 @@ __global__ __launch_bounds__(256) void partition_count_kernel(const signed char*
   if (threadIdx.x < SBR_PART_MAX) hist[blockIdx.x * SBR_PART_MAX + threadIdx.x] = h[threadIdx.x];
 }
 
+template <int EPT>
 __global__ __launch_bounds__(256) void partition_scatter_kernel(const signed char* __restrict__ pos, long R, PartSeg sg,
                                                                 const int* __restrict__ hist, int* __restrict__ slots_out) {
   __shared__ int before[SBR_PART_MAX], total[SBR_PART_MAX];
   __shared__ int wave_tot[SBR_PART_MAX][4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t < SBR_PART_MAX) {
-    int bsum = 0, tsum = 0;
-    if (hist)                       // hist == nullptr: one block covers all slots and takes the totals from its own scan below
-      for (int b = 0; b < (int)gridDim.x; ++b) {
-        const int v = hist[b * SBR_PART_MAX + t];
-        if (b < (int)blockIdx.x) bsum += v;
-        tsum += v;
+  if (t < SBR_PART_MAX) { before[t] = 0; total[t] = 0; }
+  __syncthreads();
+  if (hist) {                       // hist == nullptr: one block covers all slots and takes the totals from its own scan below
+    // per-block histograms of ALL blocks -> counts in front of this block and totals, all threads at once
+    for (int i = t; i < (int)gridDim.x * SBR_PART_MAX; i += 256) {
+      const int v = hist[i];
+      if (v) {
+        atomicAdd(&total[i & (SBR_PART_MAX - 1)], v);
+        if (i / SBR_PART_MAX < (int)blockIdx.x) atomicAdd(&before[i & (SBR_PART_MAX - 1)], v);
       }
-    before[t] = bsum;
-    total[t] = tsum;
+    }
   }
-  const long lo = (long)blockIdx.x * PART_CHUNK + t * PART_EPT;
-  signed char mine[PART_EPT];
+  const long lo = (long)blockIdx.x * (256 * EPT) + t * EPT;
+  signed char mine[EPT];
   int local[SBR_PART_MAX];
 #pragma unroll
   for (int m = 0; m < SBR_PART_MAX; ++m) local[m] = 0;
+  part_load<EPT>(pos, lo, R, (((uintptr_t)pos) & 3) == 0, mine);
 #pragma unroll
-  for (int e = 0; e < PART_EPT; ++e) {
-    mine[e] = (lo + e < R) ? pos[lo + e] : (signed char)-1;
+  for (int e = 0; e < EPT; ++e) {
 #pragma unroll
     for (int q = 0; q < SBR_PART_MAX; ++q) local[q] += (mine[e] == q);
   }
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(const signed cha
     excl[m] = w;                                              // first output position of this thread for modality m
   }
 #pragma unroll
-  for (int e = 0; e < PART_EPT; ++e) {
+  for (int e = 0; e < EPT; ++e) {
 #pragma unroll
     for (int q = 0; q < SBR_PART_MAX; ++q)
       if (mine[e] == q) slots_out[excl[q]++] = (int)(lo + e);
@@ -160,11 +177,11 @@ extern "C" int sbr_partition_slots(const signed char* pos, long R, int n_mod, co
   if (sg.offs[n_mod] == 0) return SBR_OK;
   const int nb = sbr_cdiv(R > 0 ? R : 1, PART_CHUNK);
   hipStream_t s = (hipStream_t)stream;
-  if (nb == 1) {                   // small batches: one launch (the kernel chain, not the work, bounds them)
-    partition_scatter_kernel<<<1, 256, 0, s>>>(pos, R, sg, nullptr, slots_out);
+  if (R <= 256 * PART_EPT_ONE) {   // small batches: one launch (the kernel chain, not the work, bounds them)
+    partition_scatter_kernel<PART_EPT_ONE><<<1, 256, 0, s>>>(pos, R, sg, nullptr, slots_out);
   } else {
-    partition_count_kernel<<<nb, 256, 0, s>>>(pos, R, n_mod, (int*)workspace);
-    partition_scatter_kernel<<<nb, 256, 0, s>>>(pos, R, sg, (const int*)workspace, slots_out);
+    partition_count_kernel<PART_EPT><<<nb, 256, 0, s>>>(pos, R, n_mod, (int*)workspace);
+    partition_scatter_kernel<PART_EPT><<<nb, 256, 0, s>>>(pos, R, sg, (const int*)workspace, slots_out);
   }
   SBR_CHECK_LAUNCH("sbr_partition_slots");
   return SBR_OK;

@@ -158,7 +158,7 @@ class _EntityRun:
             seg.append(seg[-1] + c)
         slots = a.i32(seg[-1])
         seg_arr = (ctypes.c_int * len(seg))(*seg)
-        ws = a.i32((R + 4095) // 4096 * 8 + 8)
+        ws = a.i32(int(ops.lib().sbr_partition_slots_workspace(R)) // 4 + 8)
         call('sbr_partition_slots', ptr(pos_dev), R, len(counts), ctypes.cast(seg_arr, ctypes.c_void_p), ptr(slots), ptr(ws),
              ws.numel() * 4, st)
         entries, tables, offs = [], [], [0]
