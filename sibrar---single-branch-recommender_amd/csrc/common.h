@@ -1,5 +1,6 @@
 // Shared helpers for the SiBraR HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -157,7 +158,9 @@ static __global__ void sbr_colred_final_kernel(double* __restrict__ ws, int KD) 
 static inline int sbr_col_reduce_blocks(long n, int D) {
   const int RL = 256 / (D >> 2);
   long b = (n + 8L * RL - 1) / (8L * RL);
-  if (b > 512) b = 512;          // one double atomic per block and column: more blocks only add contention on D addresses
+  static long cap = 0;
+  if (cap == 0) cap = getenv("SBR_COLRED_BLOCKS") ? atol(getenv("SBR_COLRED_BLOCKS")) : 512;
+  if (b > cap) b = cap;          // one double atomic per block and column: more blocks only add contention on D addresses
   return b < 1 ? 1 : (int)b;
 }
 static inline bool sbr_col_reduce_ok(const void* p, long ld, int D) {

@@ -180,7 +180,7 @@ extern "C" int sbr_bn_score_bwd_stats(const float* G, const float* U, const floa
   hipStream_t s = (hipStream_t)stream;
   const int RL = 256 / (D >> 2);
   long blocks = (B + 2L * RL - 1) / (2L * RL);               // >= 2 users per row lane
-  if (blocks > 512) blocks = 512;
+  { const long cap = getenv("SBR_COLRED_BLOCKS") ? atol(getenv("SBR_COLRED_BLOCKS")) : 512; if (blocks > cap) blocks = cap; }
   if (blocks < 1) blocks = 1;
   bn_score_bwd_stats_kernel<<<(int)blocks, 256, 0, s>>>(G, U, Z, dU, B, N, D, save_mean, save_rstd, weight, bias, ws);
   SBR_CHECK_LAUNCH("sbr_bn_score_bwd_stats");

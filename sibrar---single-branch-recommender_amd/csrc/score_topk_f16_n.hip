@@ -264,16 +264,22 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   // exclusions costs its events, not a serialised round per entry for the whole wave.
   // (a wave past the last user group — padding of the last workgroup — has no group_base entry: it runs without events)
   const bool has_excl = events != nullptr && (row0 >> 5) + wave < ((Bu + 31) >> 5);      // wave-uniform
-  const unsigned int* evp = nullptr;
+  // (read through the CONSTANT address space: hipcc turns a wave-uniform load from global memory into s_load only when it can
+  // prove that nothing in the kernel writes there; it could not, used global_load_dwordx4 + VGPRs for the window, and the wait for
+  // that load — vmcnt(0), i.e. for every candidate store in flight — sat inside the event loop: +0.28 ms per pass)
+  typedef const __attribute__((address_space(4))) unsigned int* ev_ptr;
+  typedef unsigned int ev_quad __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) ev_quad* ev_quad_ptr;
+  ev_ptr evp = nullptr;
   unsigned int w0 = S5_EV_NONE, w1 = S5_EV_NONE, w2 = S5_EV_NONE, w3 = S5_EV_NONE, n0 = S5_EV_NONE, n1 = S5_EV_NONE, n2 = S5_EV_NONE, n3 = S5_EV_NONE;
   int ev_rem = 4, ev_q = 8;
 #define S5_EV_RESTART()                                                                                                  \
   if (has_excl) {                                                                                                        \
-    const uint4 qa = *reinterpret_cast<const uint4*>(evp), qb = *reinterpret_cast<const uint4*>(evp + 4);                \
+    const ev_quad qa = *(ev_quad_ptr)(evp), qb = *(ev_quad_ptr)(evp + 4);                                                \
     w0 = qa.x; w1 = qa.y; w2 = qa.z; w3 = qa.w; n0 = qb.x; n1 = qb.y; n2 = qb.z; n3 = qb.w;                             \
     ev_rem = 4; ev_q = 8;                                                                                                \
   }
-  if (has_excl) evp = events + group_base[(row0 >> 5) + wave];
+  if (has_excl) evp = (ev_ptr)events + ((const __attribute__((address_space(4))) int*)group_base)[(row0 >> 5) + wave];
   S5_EV_RESTART()
   int peek = 0;
   int slot_next = 0;                                       // ring slot of the next tile of the sequence
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         w0 = w1; w1 = w2; w2 = w3;                                                                                       \
         if (--ev_rem == 0) {                                                                                             \
           w0 = n0; w1 = n1; w2 = n2; w3 = n3;                                                                            \
-          const uint4 qn = *reinterpret_cast<const uint4*>(evp + ev_q);                                                  \
+          const ev_quad qn = *(ev_quad_ptr)(evp + ev_q);                                                                 \
           n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w;                                                                    \
           ev_rem = 4; ev_q += 4;                                                                                         \
         }                                                                                                                \
