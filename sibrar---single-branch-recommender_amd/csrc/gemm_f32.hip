@@ -525,6 +525,48 @@ __global__ void splitk_reduce_multi_kernel(SplitkMulti a) {
   }
 }
 
+// The same with 16 bytes per lane (every N[q] a multiple of 4, slabs 16-byte aligned): a block sums 128 consecutive elements, four
+// slab loads in flight per lane. Per element the summation order is the scalar kernel's (z = zg, zg + 8, ... per group, then the
+// eight groups in order), so the results are bit-identical to it; 26 -> ~15 us for the step's three dW products (84 MB of slabs).
+__global__ __launch_bounds__(256) void splitk_reduce_multi4_kernel(SplitkMulti a) {
+  __shared__ float4 part[8][32];
+  const int q = blockIdx.y;
+  const int e_local = threadIdx.x & 31, zg = threadIdx.x >> 5;
+  const long total = (long)a.M[q] * a.N[q];
+  const long e = blockIdx.x * 128L + 4 * e_local;
+  if (blockIdx.x * 128L >= total) return;                   // uniform per workgroup
+  const float* slab = a.slab[q];
+  const int splits = a.splits[q];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total) {
+    int z = zg;
+    for (; z + 24 < splits; z += 32) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + (long)z * total + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + (long)(z + 8) * total + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(slab + (long)(z + 16) * total + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(slab + (long)(z + 24) * total + e);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; z < splits; z += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (long)z * total + e);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[zg][e_local] = acc;
+  __syncthreads();
+  if (zg == 0 && e < total) {
+    float4 v = part[0][e_local];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float4 p = part[g][e_local]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+    float* c = a.C[q] + (e / a.N[q]) * a.ldc[q] + (e % a.N[q]);           // N % 4 == 0: the four elements share a row
+    if ((((uintptr_t)c) & 15) == 0) *reinterpret_cast<float4*>(c) = v;
+    else { c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
+  }
+}
+
 // slabs / outs: HOST arrays of device pointers; ldcs, Ms, Ns, splits: HOST arrays (copied into the launch)
 extern "C" int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
                                        const int* Ns, const int* splits, void* stream) {
@@ -538,7 +580,10 @@ extern "C" int sbr_splitk_reduce_multi(int count, const void* const* slabs, cons
     const long total = (long)Ms[q] * Ns[q];
     most = total > most ? total : most;
   }
-  splitk_reduce_multi_kernel<<<dim3(sbr_cdiv(most, 32), count), 256, 0, (hipStream_t)stream>>>(a);
+  bool vec4 = true;
+  for (int q = 0; q < count; ++q) vec4 = vec4 && (Ns[q] % 4 == 0) && ((((uintptr_t)slabs[q]) & 15) == 0);
+  if (vec4) splitk_reduce_multi4_kernel<<<dim3(sbr_cdiv(most, 128), count), 256, 0, (hipStream_t)stream>>>(a);
+  else splitk_reduce_multi_kernel<<<dim3(sbr_cdiv(most, 32), count), 256, 0, (hipStream_t)stream>>>(a);
   SBR_CHECK_LAUNCH("sbr_splitk_reduce_multi");
   return SBR_OK;
 }
