@@ -26,3 +26,9 @@ struct GemmArgs {
 // the tile kernel), otherwise SBR_OK / an error code. g.k_chunk and g.splits must be set; g.slab / g.atomic as for the tile
 // kernel.
 int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s);
+
+// gemm_tn_direct_f32.hip: weight-gradient products (M = 128, N = 128 j, long K) straight from global memory, one slab per workgroup.
+// sbr_tn_direct_splits: slabs it would write (0: shape not eligible); sbr_tn_direct_launch returns -1 when not eligible.
+int sbr_tn_direct_splits(const float* A, long lda, int M, int N, int K);
+int sbr_tn_direct_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
+                         float* slab, int* splits_out, hipStream_t s);

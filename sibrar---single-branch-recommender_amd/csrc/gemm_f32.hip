@@ -453,6 +453,14 @@ static int tn_slabs(const float* A, long lda, const int* a_idx, const float* B, 
                     void* workspace, long workspace_bytes, int* splits_out, hipStream_t s) {
   int splits = tn_splits(M, N, K);
   SBR_REQUIRE(workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float), "sbr_gemm_tn_f32: workspace too small");
+  {
+    // the training step's dW shapes: operands straight from global memory into the MFMAs, one slab per workgroup
+    const int ds = sbr_tn_direct_splits(A, lda, M, N, K);
+    if (ds > 0 && (long)ds * M * N * (long)sizeof(float) <= workspace_bytes) {
+      const int rc = sbr_tn_direct_launch(A, lda, a_idx, B, ldb, b_idx, M, N, K, (float*)workspace, splits_out, s);
+      if (rc >= 0) return rc;
+    }
+  }
   GemmArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.bias = nullptr;
   g.C = nullptr; g.ldc = N; g.c_idx = nullptr; g.M = M; g.N = N; g.K = K; g.act = SBR_ACT_NONE;

@@ -743,3 +743,34 @@ def test_split_projector_gemm_has_the_error_of_the_fp32_pipe(M, K, monkeypatch):
         if i < 3:
             assert bool((res[True][i].cpu()[untouched] == 123.0).all())        # rows outside c_idx are not written
     assert bool(((res[True][2].double().cpu()[ci] - res[False][2].double().cpu()[ci]).abs() <= 2.0 ** -19 * absum + 1e-6).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,gather', [(128, 9001, False), (768, 8200, True), (256, 20011, True)])
+def test_direct_tn_kernel_matches_fp64_and_the_ring_kernel(N, K, gather, monkeypatch):
+    """sbr_gemm_tn_f32 on the weight-gradient shapes (M = 128, N = 128 j, long K) takes the LDS-free direct kernel
+    (csrc/gemm_tn_direct_f32.hip): against an fp64 product and next to the ring kernel (SBR_TN_DIRECT=0) on the same call — plain
+    and row-gathered operands, K ranges that end inside a 16-row step, the deferred-slab path summed by sbr_splitk_reduce_multi."""
+    ops = S().ops
+    g = torch.Generator().manual_seed(9)
+    n_src = 5000
+    dz = _rand(K, 128, seed=61).to(DEV)
+    x = _rand(n_src if gather else K, N, seed=62).to(DEV)
+    b_idx = torch.randint(0, n_src, (K,), generator=g, dtype=torch.int32).to(DEV) if gather else None
+    xd = x.double().cpu()[b_idx.cpu().long()] if gather else x.double().cpu()
+    want = dz.double().cpu().t() @ xd
+    mag = dz.double().cpu().abs().t() @ xd.abs()
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SBR_TN_DIRECT', flag)
+        got[flag] = ops.matmul_tn(dz, x, b_idx=b_idx, n_rows=K).double().cpu()
+    e_direct = ((got['1'] - want).abs() / mag).max().item()
+    e_ring = ((got['0'] - want).abs() / mag).max().item()
+    assert e_direct <= max(2.0 * e_ring, 2.0 ** -20), (e_direct, e_ring)
+    # deferred slabs + the shared reducer give the same bits as the immediate reduction (same slabs, same summation order)
+    monkeypatch.setenv('SBR_TN_DIRECT', '1')
+    d = ops.DeferredTN()
+    out = torch.empty(128, N, device=DEV)
+    d.matmul_tn('t', dz, x, b_idx=b_idx, n_rows=K, out=out)
+    d.finish()
+    assert torch.equal(out.double().cpu(), got['1'])
