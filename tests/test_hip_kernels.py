@@ -774,3 +774,43 @@ def test_direct_tn_kernel_matches_fp64_and_the_ring_kernel(N, K, gather, monkeyp
     d.matmul_tn('t', dz, x, b_idx=b_idx, n_rows=K, out=out)
     d.finish()
     assert torch.equal(out.double().cpu(), got['1'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('D', [128, 256])
+def test_fused_f16_scorer_long_tailed_exclusion_rows(D):
+    """The exclusion event stream of the narrow-wave kernel (csrc/score_topk_f16_n.hip) on rows of very different lengths: users
+    without exclusions, users with thousands (many events per item tile, several event quads per tile), users whose WHOLE shard is
+    excluded (fewer than k candidates: -inf / -1 padding), a shuffled user -> CSR-row map, and a shard window in the middle of the
+    catalogue — against the fp64 product of the same fp16 values with the mask applied densely."""
+    ops = S().ops
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    Bu, I_all, off, I, k = 2500, 9000, 3000, 4000, 20
+    u = (_rand(Bu, D, seed=90) / 4).half()
+    it = (_rand(I_all, D, seed=91) / 4).half()
+    deg = np.minimum(I_all, rng.lognormal(3.0, 1.6, size=Bu).astype(np.int64))
+    deg[:40] = 0                                               # no exclusions at all
+    deg[40:48] = I_all                                         # everything excluded
+    deg[48:60] = rng.integers(3000, 6000, size=12)             # thousands
+    rows = np.repeat(np.arange(Bu), deg)
+    cols = np.concatenate([np.sort(rng.choice(I_all, size=d, replace=False)) for d in deg]) if rows.size else np.zeros(0, np.int64)
+    m = sp.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(Bu, I_all))
+    m.sort_indices()
+    perm = rng.permutation(Bu)                                 # scored row b uses CSR row perm[b]
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(DEV)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(DEV)
+    uidx = torch.from_numpy(perm.astype(np.int64)).to(DEV)
+    val, idx = ops.score_topk_f16(u.to(DEV), it[off:off + I].contiguous().to(DEV), k, uidx, indptr, indices, item_offset=off)
+    ref = u.double() @ it[off:off + I].double().t()
+    dense = torch.from_numpy(m[perm][:, off:off + I].toarray() != 0)
+    ref[dense] = -float('inf')
+    tv, ti = torch.topk(ref, k, sorted=True)
+    val, idx = val.cpu(), idx.cpu()
+    finite = ~torch.isinf(tv)
+    close(val[finite], tv[finite], rtol=1e-5, atol=1e-5, what='fused values')
+    assert bool(torch.isinf(val[~finite]).all()) and bool((val[~finite] < 0).all())
+    assert bool((idx[~finite] == -1).all()), 'slots behind the last candidate must carry index -1'
+    got = torch.gather(ref, 1, (idx.long() - off).clamp_min(0))
+    close(got[finite], tv[finite], rtol=1e-5, atol=1e-5, what='scores of the selected items')
+    assert bool(((idx[finite] >= off) & (idx[finite] < off + I)).all())
