@@ -445,7 +445,10 @@ static int tn_splits(int M, int N, int K) {
 }
 
 extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
-  return (long)tn_splits(M, N, K) * M * N * (long)sizeof(float);
+  int splits = tn_splits(M, N, K);
+  const int ds = sbr_tn_direct_splits(nullptr, 0, M, N, K);           // the opt-in direct kernel cuts K its own way
+  if (ds > splits) splits = ds;
+  return (long)splits * M * N * (long)sizeof(float);
 }
 
 // slab pass of the TN product: partial tiles slab[z][M][N] for z < *splits_out (plain stores), no reduction

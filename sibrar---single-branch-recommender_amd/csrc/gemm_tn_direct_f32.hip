@@ -174,7 +174,7 @@ int sbr_tn_direct_splits(const float* A, long lda, int M, int N, int K) {
   // 20 us of the large product are HBM latency that three steps of prefetch (24 KB per wave) do not cover. Kept for the record
   // and for its test; the ring kernel stays the product path.
   if (!(getenv("SBR_TN_DIRECT") && atoi(getenv("SBR_TN_DIRECT")) == 1)) return 0;
-  if (M != 128 || N < 128 || N % 128 != 0 || K < 8192 || !td_al16(A, lda)) return 0;      // (B is checked at the launch)
+  if (M != 128 || N < 128 || N % 128 != 0 || K < 8192 || (A && !td_al16(A, lda))) return 0;      // (A == NULL: shape query; B is checked at the launch)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
