@@ -1,9 +1,11 @@
-"""Cycle stamps of the fused scorer (SBR_ST_DEBUG=4): per consumer wave total cycles, time waiting for tiles, time in candidate
+"""Cycle stamps of the EARLIER fused scorer kernels (SBR_SCORER_V3=1 is set here; the narrow-wave kernel that replaced them is
+measured by tools/scorer_lab.py) (SBR_ST_DEBUG=4): per consumer wave total cycles, time waiting for tiles, time in candidate
 blocks, compaction time and counts. D = 64 | 128: the 64-users-per-wave kernel (448 users per workgroup); D = 256 or
 SBR_SCORER_V1=1: the 32-users-per-wave kernel (224 users per workgroup; fields: total, wait, events, overflow)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('SBR_ST_DEBUG', '4')
+os.environ.setdefault('SBR_SCORER_V3', '1')
 import torch, numpy as np
 import sibrar_amd as S
 from importlib import import_module
