@@ -301,7 +301,7 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
 // With v_mfma_f32_32x32x2_f32 this product (45,824 x 128 x 768 at the bench's batch) is bound by the fp32 matrix pipe: 57 us of
 // pipe time, 96 us measured; here it needs 6 x 1/16 of that and reads 141 MB of feature rows.
 #ifndef PJ_ABL
-#define PJ_ABL 0                         // lab: 1 no MFMAs, 2 planes written once, 3 one A half block only, 4 = 2 + 3
+#define PJ_ABL 0                         // lab (timing only): 2 weight planes written once, 3 the first two A chunks only, 4 = 2 + 3
 #endif
 struct ProjArgs {
   const float* A; long lda; const int* a_idx;
@@ -435,13 +435,13 @@ _Pragma("unroll") \
  \
       const int c2 = c + 2, it2 = c2 / KC, kc2 = c2 - it2 * KC; \
       const int blk2 = gw + it2 * nw; \
-      if (c2 < n_steps && blk2 < n_blocks) { \
+      if (PJ_ABL != 3 && PJ_ABL != 4 && c2 < n_steps && blk2 < n_blocks) { \
         if (kc2 == 0) { if (it2 & 1) ap1 = row_ptr(blk2); else ap0 = row_ptr(blk2); } \
         load_chunk((it2 & 1) ? ap1 : ap0, kc2, fill); \
       } \
       mult_chunk(c & 1, cur); \
     } \
-    if (c + 1 < n_steps) { \
+    if (PJ_ABL != 2 && PJ_ABL != 4 && c + 1 < n_steps) { \
       store_w((c + 1) & 1); \
       if (c + 2 < n_steps) load_w((kc + 2) % KC); \
     } \
