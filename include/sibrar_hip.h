@@ -230,6 +230,10 @@ int sbr_bn_train_bwd(const float* dY, const float* Y, const float* X, float* dX,
  * normalises on the fly: sbr_bn_score_fwd). */
 int sbr_bn_train_stats(const float* X, long n, int D, float* running_mean, float* running_var, long* num_batches_tracked,
                        float* save_mean, float* save_rstd, double* ws, float eps, float momentum, void* stream);
+/* the same statistics from sums that the producing GEMM left pending in `ws` (sbr_gemm_split_f32, mode 0, colsum_ws != NULL: per-column
+ * sums and sums of squares of its output in the column-reduction replica layout): no pass over the BatchNorm's input at all */
+int sbr_bn_finalize_stats(long n, int D, float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
+                          float* save_rstd, double* ws, float eps, float momentum, void* stream);
 
 /* ---- trailing BatchNorm1d fused with the training scorer (one modality per slot) — algorithms/sgd_alg.py:1834-1837,
  * 1871-1877 (sb_net's trailing BatchNorm1d, no activation) followed by einsum('be,bce->bc') sgd_alg.py:2114, forward and

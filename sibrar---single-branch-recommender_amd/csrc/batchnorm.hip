@@ -124,6 +124,17 @@ extern "C" int sbr_bn_train_stats(const float* X, long n, int D, float* running_
                         (hipStream_t)stream);
 }
 
+// second half of sbr_bn_train_stats for statistics that a producer kernel has already left pending in `ws` (the NT GEMM in front
+// of the BatchNorm: sbr_gemm_split_f32 mode 0 with colsum_ws): batch mean / rstd of the n rows, running-statistics update
+extern "C" int sbr_bn_finalize_stats(long n, int D, float* running_mean, float* running_var, long* num_batches_tracked,
+                                     float* save_mean, float* save_rstd, double* ws, float eps, float momentum, void* stream) {
+  SBR_REQUIRE(save_mean && save_rstd && ws && n >= 1 && D >= 1, "sbr_bn_finalize_stats: bad arguments");
+  bn_finalize_kernel<<<sbr_cdiv(D, 256), 256, 0, (hipStream_t)stream>>>(ws, n, D, eps, momentum, save_mean, save_rstd, running_mean,
+                                                                        running_var, num_batches_tracked);
+  SBR_CHECK_LAUNCH("sbr_bn_finalize_stats");
+  return SBR_OK;
+}
+
 extern "C" int sbr_bn_eval_fwd(const float* X, float* Y, long n, int D, const float* weight, const float* bias,
                                const float* running_mean, const float* running_var, float eps, int act, void* stream) {
   if (n == 0) return SBR_OK;

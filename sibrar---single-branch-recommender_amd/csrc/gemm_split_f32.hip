@@ -76,7 +76,9 @@ __device__ __forceinline__ sp_f32x16 sp_mfma(const sp_u32x4 a, const sp_u32x4 b,
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sp_bf16x8, a), __builtin_bit_cast(sp_bf16x8, b), c, 0, 0, 0);
 }
 
-// MODE 0: NT (W is [n][k]); MODE 1: NN (W is [k][n]). EPI 0: bias + activation; EPI 1: activation derivative of Y + column sums.
+// MODE 0: NT (W is [n][k]); MODE 1: NN (W is [k][n]). EPI 0: bias + activation; EPI 1: activation derivative of Y + column sums;
+// EPI 2 (MODE 0): EPI 0 + per-column sums and sums of squares of what is stored (the batch statistics of a BatchNorm that follows,
+// left pending in colsum_ws in the replica layout of sbr_col_reduce<2>: the separate statistics pass over the output is not needed).
 template <int MODE, int EPI>
 __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs g, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
     *(sp_lds_u32x4*)(smem + 2 * SP_PLANE + off) = p2;
   }
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == 0) {
+  if constexpr (EPI == 0 || EPI == 2) {
     if (g.bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) bj[j] = g.bias[j * 32 + l31];
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
   __syncthreads();                                               // the only barrier of the kernel
 
   const unsigned char* wfrag = smem + lane * 16;
-  double cs[4] = {0.0, 0.0, 0.0, 0.0};                           // EPI 1: running column sums of columns 32 j + l31 over this lane's rows
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};                           // EPI 1 / 2: running column sums of columns 32 j + l31 over this lane's rows
+  double cq[4] = {0.0, 0.0, 0.0, 0.0};                           // EPI 2: ... of their squares
 
   sp_f32x16 acc[4];
   auto mult_half = [&](int h, const float4 (&raw)[4][2]) {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
       if constexpr (KIND == 3) yp = g.Y + (m0 + 4 * half) * g.ldy + l31;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float ts = 0.f;
+        float ts = 0.f, tq = 0.f;
         float yv[16];
         if constexpr (KIND == 3) {
 #pragma unroll
@@ -214,9 +217,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
             v = v * sbr_act_grad_from_out(yv[r], g.act);
             if (FULL || lr < rows_left) ts += v;
           }
+          if constexpr (EPI == 2) {
+            if (FULL || lr < rows_left) { ts += v; tq += v * v; }
+          }
           if (FULL || lr < rows_left) cp[(long)lr * g.ldc + j * 32] = v;
         }
-        if constexpr (KIND == 3) cs[j] += (double)ts;
+        if constexpr (KIND == 3 || EPI == 2) cs[j] += (double)ts;
+        if constexpr (EPI == 2) cq[j] += (double)tq;
       }
     };
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
@@ -230,6 +237,15 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
       if (full) finish(T1{}, std::true_type{}); else finish(T1{}, std::false_type{});
     } else {
       if (full) finish(T2{}, std::true_type{}); else finish(T2{}, std::false_type{});
+    }
+  }
+  if constexpr (EPI == 2) {
+    // replica layout of sbr_col_reduce<2>: [1 + replica][2][128] doubles (sums, then sums of squares)
+    double* rep = g.colsum_ws + (long)(1 + (gw % SBR_COLRED_REP)) * 2 * SP_N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double o = cs[j] + __shfl_xor(cs[j], 32, 64), q = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (half == 0) { atomicAdd(rep + j * 32 + l31, o); atomicAdd(rep + SP_N + j * 32 + l31, q); }
     }
   }
   if constexpr (EPI == 1) {
@@ -253,6 +269,8 @@ extern "C" int sbr_gemm_split_supported(long M, int N, int K) { return M >= 1 &&
 // multiplications run on the bf16 matrix pipe over exact three-way splits of both operands (six terms, fp32 accumulate).
 // Y != NULL (mode 1 only): C = (A W) * act'(Y) with `act` the activation whose OUTPUT Y is, and colsum_ws (17 * 128 doubles,
 // contract of sbr_colsum / sbr_colred_finish, may be NULL) receives the pending column sums of C.
+// mode 0 with colsum_ws != NULL (17 * 2 * 128 doubles, zero on entry like every column-reduction workspace): the per-column sums
+// and sums of squares of C are left pending there (sbr_bn_finalize_stats turns them into the statistics of the BatchNorm behind C).
 extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
                                   long M, int N, int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream) {
   SBR_REQUIRE(mode == 0 || mode == 1, "sbr_gemm_split_f32: mode %d", mode);
@@ -260,7 +278,7 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
   SBR_REQUIRE(sbr_gemm_split_supported(M, N, K), "sbr_gemm_split_f32: shape %ld x %d x %d not supported (N = K = 128)", M, N, K);
   SBR_REQUIRE(A && W && C, "sbr_gemm_split_f32: null operand");
   SBR_REQUIRE(sp_al16(A, lda) && (mode == 1 || sp_al16(W, ldw)), "sbr_gemm_split_f32: operands must be 16-byte aligned");
-  SBR_REQUIRE(!(Y && mode == 0) && !(colsum_ws && !Y) && !(Y && bias), "sbr_gemm_split_f32: Y / colsum_ws belong to mode 1 without bias");
+  SBR_REQUIRE(!(Y && mode == 0) && !(colsum_ws && !Y && mode == 1) && !(Y && bias), "sbr_gemm_split_f32: Y belongs to mode 1 without bias");
   SplitArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.act = act; g.Y = Y; g.ldy = ldy;
   g.colsum_ws = colsum_ws;
@@ -281,7 +299,8 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
     }                                                                                                                      \
     gemm_split_kernel<MODE, EPI><<<grid, 64 * SP_WAVES, lds, s>>>(g, n_blocks);                                            \
   } while (0)
-  if (mode == 0) SP_LAUNCH(0, 0);
+  if (mode == 0 && colsum_ws) SP_LAUNCH(0, 2);
+  else if (mode == 0) SP_LAUNCH(0, 0);
   else if (Y) SP_LAUNCH(1, 1);
   else SP_LAUNCH(1, 0);
 #undef SP_LAUNCH

@@ -201,10 +201,20 @@ class _EntityRun:
             call('sbr_dropout_dev', ptr(x), ptr(xd), x.numel(), float(self.p_drop), ptr(seed[0]), int(seed[1]), st)
             self.seed, x = seed, xd
         self.acts = []                                   # per layer: (input, pre-BN output | None, output, mean, rstd)
-        for lin, bn, act in self.layers:
+        # statistics of the trailing BatchNorm from the epilogue of the GEMM in front of it (fused tail only: nothing but the
+        # statistics is needed from that pass over the output)
+        tail_stats = (self.trailing is not None and self.fuse_tail and k == 1 and not self.reg and bool(self.layers)
+                      and self.layers[-1][1] is None and ops.lib().sbr_bn_score_supported(int(self.layers[-1][0].weight.shape[0])))
+        self._stats_folded = False
+        for li, (lin, bn, act) in enumerate(self.layers):
             w = lin.weight
             if bn is None:
-                y = ops.linear_nt(x, w, lin.bias, act, out=a.f32(R, w.shape[0]))
+                out_l = a.f32(R, w.shape[0])
+                if tail_stats and li == len(self.layers) - 1 and ops.linear_nt_stats_ok(x, w, out_l):
+                    y = ops.linear_nt(x, w, lin.bias, act, out=out_l, stats_ws=self._bn_ws(self.trailing, w.shape[0]))
+                    self._stats_folded = True
+                else:
+                    y = ops.linear_nt(x, w, lin.bias, act, out=out_l)
                 self.acts.append((x, None, y, None, None))
             else:
                 z = ops.linear_nt(x, w, lin.bias, 0, out=a.f32(R, w.shape[0]))
@@ -218,8 +228,12 @@ class _EntityRun:
                 # statistics only: the scorer normalises on the fly (FusedTrainStep._phase1), nothing else reads the output
                 bn, n_, D_ = self.trailing, x.shape[0], x.shape[1]
                 mean, rstd = a.f32(D_), a.f32(D_)
-                call('sbr_bn_train_stats', ptr(x), n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
-                     ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
+                if self._stats_folded:
+                    call('sbr_bn_finalize_stats', n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                         ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
+                else:
+                    call('sbr_bn_train_stats', ptr(x), n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                         ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
                 self.tail = (x, mean, rstd)
                 self.e = None
                 self.reg_loss = None

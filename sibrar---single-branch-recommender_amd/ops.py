@@ -99,18 +99,31 @@ def _wres_ok(M, N, K, *tensors) -> bool:
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
 
 
-def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None):
+def linear_nt_stats_ok(x, W, out) -> bool:
+    """True when ``linear_nt(x, W, ..., out=out, stats_ws=ws)`` can leave the batch statistics of its output pending in ``ws``
+    (the bf16-split kernel takes the product: N = K = 128, no gathers, enough rows)."""
+    M, (N, K) = x.shape[0], W.shape
+    return _wres_ok(M, N, K, x, W, out) and _mlp_kernel(M, N, K) == 'sbr_gemm_split_f32'
+
+
+def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None, stats_ws=None):
     """out[ci(m)] = act(x[ai(m)] @ W^T + bias). W: [N, K] with arbitrary row stride (column-major weights are handled by
-    the caller through csr kernels, not here)."""
+    the caller through csr kernels, not here). ``stats_ws`` (check ``linear_nt_stats_ok`` first): a zeroed column-reduction
+    workspace of 17 * 2 * N doubles that receives the per-column sums and sums of squares of ``out`` (``bn_finalize_stats``)."""
     M = n_rows if n_rows is not None else (a_idx.numel() if a_idx is not None else x.shape[0])
     N, K = W.shape
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     if a_idx is None and c_idx is None and _wres_ok(M, N, K, x, W, out):
+        kern = _mlp_kernel(M, N, K)
+        if stats_ws is not None and kern != 'sbr_gemm_split_f32':
+            raise ValueError('linear_nt(stats_ws=...): this product does not take the kernel with the statistics epilogue')
         _timed(('gemm_f32', 0, M, N, K, False),
-               lambda: call(_mlp_kernel(M, N, K), 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
-                            act, None, 0, None, stream()))
+               lambda: call(kern, 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                            act, None, 0, ptr(stats_ws), stream()))
         return out
+    if stats_ws is not None:
+        raise ValueError('linear_nt(stats_ws=...): this product does not take the kernel with the statistics epilogue')
     if (_SPLIT and M >= _SPLIT_MIN_ROWS and lib().sbr_gemm_split_proj_supported(int(M), int(N), int(K))
             and all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in (x, W)) and out.stride(1) == 1):
         # dense modality projector (N = 128, K = 768 / 1024 / 2048 ...) on the bf16 matrix pipe, gather and scatter fused

@@ -814,3 +814,40 @@ def test_fused_f16_scorer_long_tailed_exclusion_rows(D):
     got = torch.gather(ref, 1, (idx.long() - off).clamp_min(0))
     close(got[finite], tv[finite], rtol=1e-5, atol=1e-5, what='scores of the selected items')
     assert bool(((idx[finite] >= off) & (idx[finite] < off + I)).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,act', [(4096, 0), (9001, 1)])
+def test_split_gemm_statistics_epilogue_feeds_batchnorm(M, act, monkeypatch):
+    """sbr_gemm_split_f32 (mode 0) with a statistics workspace: the per-column sums / sums of squares of its output, completed by
+    sbr_bn_finalize_stats, are the batch mean / rstd and running-statistics update that sbr_bn_train_stats computes from a pass of
+    its own over the same output (ragged last block, with and without activation)."""
+    mod = S()
+    from importlib import import_module
+    ops, lib_ = mod.ops, import_module(mod.ops.__name__.rsplit('.', 1)[0] + '._lib')
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    x, w, b = _rand(M, 128, seed=71).to(DEV), (_rand(128, 128, seed=72) / 8).to(DEV), _rand(128, seed=73).to(DEV)
+    out = torch.empty(M, 128, device=DEV)
+    assert ops.linear_nt_stats_ok(x, w, out)
+    ws = torch.zeros(ops.COLRED_WS_FACTOR * 2 * 128, device=DEV, dtype=torch.float64)
+    ops.linear_nt(x, w, b, act, out=out, stats_ws=ws)
+    plain = ops.linear_nt(x, w, b, act)
+    assert torch.equal(out, plain)                              # the epilogue does not change what is stored
+    res = {}
+    for tag in ('folded', 'own pass'):
+        rm, rv, nbt = torch.zeros(128, device=DEV), torch.ones(128, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        mean, rstd = torch.empty(128, device=DEV), torch.empty(128, device=DEV)
+        if tag == 'folded':
+            lib_.call('sbr_bn_finalize_stats', M, 128, rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      ws.data_ptr(), ops.BN_EPS, ops.BN_MOMENTUM, lib_.stream())
+        else:
+            ws2 = torch.zeros_like(ws)
+            lib_.call('sbr_bn_train_stats', out.data_ptr(), M, 128, rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), mean.data_ptr(),
+                      rstd.data_ptr(), ws2.data_ptr(), ops.BN_EPS, ops.BN_MOMENTUM, lib_.stream())
+        res[tag] = [t.cpu() for t in (mean, rstd, rm, rv, nbt)]
+    od = out.double().cpu()
+    close(res['folded'][0], od.mean(0).float(), rtol=1e-5, atol=1e-6, what='batch mean')
+    close(res['folded'][1], (1.0 / torch.sqrt(od.var(0, unbiased=False) + ops.BN_EPS)).float(), rtol=1e-5, atol=1e-6, what='batch rstd')
+    for a_, b_, what in zip(res['folded'], res['own pass'], ('mean', 'rstd', 'running mean', 'running var', 'batches')):
+        close(a_.double(), b_.double(), rtol=1e-6, atol=1e-7, what=what)
+    assert float(ws[2 * 128:].abs().max()) == 0.0                # replicas left zeroed for the next use
