@@ -109,15 +109,20 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
   // of lane (n & 31) + 32 (kc & 1) in fragment (column tile n >> 5, k step kc >> 1). 2048 chunks, 4 per thread.
 #pragma unroll
   for (int i = 0; i < 2048 / (64 * SP_WAVES); ++i) {
-    const int c = t + i * 64 * SP_WAVES;
     int n, kc;
     float4 lo, hi;
-    if constexpr (MODE == 0) {                                   // rows of W are contiguous in k: 16 consecutive threads read one row
-      n = c >> 4; kc = c & 15;
+    if constexpr (MODE == 0) {
+      // rows of W are contiguous in k. A wave-instruction handles ONE operand fragment (column tile j, k step ks): lane L reads the
+      // 8 values W(32 j + (L & 31), 16 ks + 8 (L >> 5) .. + 7) and writes its 16 bytes at lane position L of the fragment —
+      // consecutive lanes, consecutive LDS addresses. (Thread order along k — 16 consecutive threads per row — makes 16 lanes write
+      // 512 bytes apart: a 16-way bank conflict on every ds_write_b128 of the set-up.)
+      const int f = wave * 4 + i;                                // fragments 4 w .. 4 w + 3 of the 32
+      n = (f >> 3) * 32 + l31; kc = (f & 7) * 2 + half;
       const float* p = g.W + (long)n * g.ldw + kc * 8;
       lo = *reinterpret_cast<const float4*>(p);
       hi = *reinterpret_cast<const float4*>(p + 4);
     } else {                                                     // rows of W are contiguous in n: consecutive threads read consecutive n
+      const int c = t + i * 64 * SP_WAVES;
       n = c & 127; kc = c >> 7;
       const float* p = g.W + (long)(kc * 8) * g.ldw + n;
       lo = make_float4(p[0], p[g.ldw], p[2 * g.ldw], p[3 * g.ldw]);
