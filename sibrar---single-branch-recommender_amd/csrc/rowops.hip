@@ -259,10 +259,49 @@ __global__ __launch_bounds__(256) void scatter_add_rows_pow2_kernel(const float*
   atomicAdd(&dW[(long)rows[j] * ldw + c], dOut[i * ldo + c]);
 }
 
+// D = 128, many rows: persistent waves, each takes rows w, w + W, ... four at a time — the four (source row, table row) index pairs
+// first, then the eight 256-byte halves of the four gradient rows, then eight atomic instructions back to back (a wave-instruction
+// adds 256 contiguous bytes of one destination row). The one-element-per-thread kernel above issues ONE atomic per wave behind a
+// chain of three dependent loads and a wave launch; this one keeps eight in flight per wave.
+__global__ __launch_bounds__(256) void scatter_add_rows128_kernel(const float* __restrict__ dOut, long ldo, const int* __restrict__ in_idx,
+                                                                  const int* __restrict__ rows, float* __restrict__ dW, long ldw, long n) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+  for (long j0 = wid * 4; j0 < n; j0 += nw * 4) {
+    long src[4], dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long j = j0 + q < n ? j0 + q : n - 1;
+      src[q] = in_idx ? in_idx[j] : j;
+      dst[q] = rows[j];
+    }
+    float v[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q][0] = dOut[src[q] * ldo + lane];
+      v[q][1] = dOut[src[q] * ldo + 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j0 + q < n) {                                          // wave-uniform
+        atomicAdd(&dW[dst[q] * ldw + lane], v[q][0]);
+        atomicAdd(&dW[dst[q] * ldw + 64 + lane], v[q][1]);
+      }
+    }
+  }
+}
+
 extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW,
                                     long ldw, long n, int D, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(dOut && rows && dW, "sbr_scatter_add_rows: null operand");
+  if (D == 128 && n >= 4096 && !(getenv("SBR_SCATTER_V1") && atoi(getenv("SBR_SCATTER_V1")) != 0)) {
+    int blocks = (int)sbr_cdiv(n, 16);                           // >= 4 rows per wave
+    if (blocks > 2048) blocks = 2048;                            // 8 workgroups of 4 waves per CU
+    scatter_add_rows128_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n);
+    SBR_CHECK_LAUNCH("sbr_scatter_add_rows");
+    return SBR_OK;
+  }
   if (D >= 16 && D <= 256 && (D & (D - 1)) == 0) {
     int log2d = 0;
     while ((1 << log2d) < D) ++log2d;

@@ -1,0 +1,30 @@
+import os, sys
+sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/tools') else os.getcwd())
+import torch
+import sibrar_amd as S
+from importlib import import_module
+L = import_module('sibrar---single-branch-recommender_amd._lib')
+dev='cuda'
+g = torch.Generator(device=dev).manual_seed(0)
+n, D = 45824, 128
+d = torch.randn(90113, D, device=dev, generator=g)
+slots = torch.randperm(90112, device=dev, generator=g)[:n].to(torch.int32)
+rows = torch.randint(0, 50000, (n,), device=dev, generator=g, dtype=torch.int32)
+def run(out):
+    L.call('sbr_scatter_add_rows', d.data_ptr(), D, slots.data_ptr(), rows.data_ptr(), out.data_ptr(), D, n, D, L.stream())
+res = {}
+for flag in ('1', '0'):
+    os.environ['SBR_SCATTER_V1'] = flag
+    out = torch.zeros(50000, D, device=dev)
+    run(out); res[flag] = out.clone()
+    for _ in range(5): run(out)
+    evs=[]
+    for _ in range(20):
+        a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+        a.record(); run(out); b.record(); evs.append((a,b))
+    torch.cuda.synchronize()
+    ts=sorted(x.elapsed_time(y) for x,y in evs)
+    print('SBR_SCATTER_V1=%s: %.1f us' % (flag, ts[len(ts)//2]*1e3))
+ref = torch.zeros(50000, D, device=dev, dtype=torch.float64)
+ref.index_add_(0, rows.long(), d[slots.long()].double())
+print('max err new %.3g old %.3g' % (float((res['0'].double()-ref).abs().max()), float((res['1'].double()-ref).abs().max())))
