@@ -28,3 +28,26 @@ for flag in ('1', '0'):
 ref = torch.zeros(50000, D, device=dev, dtype=torch.float64)
 ref.index_add_(0, rows.long(), d[slots.long()].double())
 print('max err new %.3g old %.3g' % (float((res['0'].double()-ref).abs().max()), float((res['1'].double()-ref).abs().max())))
+
+# cold destination: a 512 MB write between two runs pushes the table gradient out of L2 / the Infinity Cache (as the rest of a
+# training step does between the gradient reset and the scatter)
+big = torch.empty(128 * 1024 * 1024, device=dev)
+for flag in ('1', '0'):
+    os.environ['SBR_SCATTER_V1'] = flag
+    out = torch.zeros(50000, D, device=dev)
+    ts = []
+    for _ in range(12):
+        big.fill_(1.0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(out); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    ts.sort()
+    print('cold destination, SBR_SCATTER_V1=%s: %.1f us' % (flag, ts[len(ts) // 2] * 1e3))
+    # warm again: zero the table right before the scatter (the zeros stay in the Infinity Cache)
+    ts = []
+    for _ in range(12):
+        big.fill_(1.0)
+        out.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(out); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    ts.sort()
+    print('zeroed just before, SBR_SCATTER_V1=%s: %.1f us' % (flag, ts[len(ts) // 2] * 1e3))
