@@ -32,3 +32,9 @@ int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s);
 int sbr_tn_direct_splits(const float* A, long lda, int M, int N, int K);
 int sbr_tn_direct_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                          float* slab, int* splits_out, hipStream_t s);
+
+// gemm_split_tn_f32.hip: the same products on the bf16 matrix pipe (exact three-way split of both operands, six MFMA terms), one slab
+// per workgroup. sbr_tn_split_splits: slabs it would write (0: shape not eligible or SBR_GEMM_SPLIT=0 / SBR_TN_SPLIT=0).
+int sbr_tn_split_splits(int M, int N, int K);
+int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
+                        float* slab, int* splits_out, hipStream_t s);

@@ -448,6 +448,8 @@ extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
   int splits = tn_splits(M, N, K);
   const int ds = sbr_tn_direct_splits(nullptr, 0, M, N, K);           // the opt-in direct kernel cuts K its own way
   if (ds > splits) splits = ds;
+  const int ss = sbr_tn_split_splits(M, N, K);                         // so does the bf16-split kernel
+  if (ss > splits) splits = ss;
   return (long)splits * M * N * (long)sizeof(float);
 }
 
@@ -457,7 +459,15 @@ static int tn_slabs(const float* A, long lda, const int* a_idx, const float* B, 
   int splits = tn_splits(M, N, K);
   SBR_REQUIRE(workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float), "sbr_gemm_tn_f32: workspace too small");
   {
-    // the training step's dW shapes: operands straight from global memory into the MFMAs, one slab per workgroup
+    // the training step's dW shapes (M = 128, N = 128 j, thousands of rows) on the bf16 matrix pipe
+    const int ss = sbr_tn_split_splits(M, N, K);
+    if (ss > 0 && (long)ss * M * N * (long)sizeof(float) <= workspace_bytes) {
+      const int rc = sbr_tn_split_launch(A, lda, a_idx, B, ldb, b_idx, M, N, K, (float*)workspace, splits_out, s);
+      if (rc >= 0) return rc;
+    }
+  }
+  {
+    // opt-in experiment: operands straight from global memory into the fp32 MFMAs, one slab per workgroup
     const int ds = sbr_tn_direct_splits(A, lda, M, N, K);
     if (ds > 0 && (long)ds * M * N * (long)sizeof(float) <= workspace_bytes) {
       const int rc = sbr_tn_direct_launch(A, lda, a_idx, B, ldb, b_idx, M, N, K, (float*)workspace, splits_out, s);

@@ -22,20 +22,13 @@
 //   * the next half block is in flight while the current one is multiplied (two 32-register raw buffers);
 //   * epilogue options of the training step as in gemm_wres_f32.hip: bias + activation (forward); multiply by the activation
 //     derivative of a second matrix Y and accumulate column sums (backward: dZ_prev = (dZ W) * act'(Y) and its bias gradient).
-#include "gemm_args.h"
+#include "gemm_split_common.h"
 #include <type_traits>
 
 #define SP_N 128
 #define SP_K 128
 #define SP_WAVES 8
 #define SP_PLANE (4 * 8 * 64 * 16)           // bytes of one bf16 plane of W in fragment order: [4 column tiles][8 k steps][64 lanes][8 bf16]
-
-typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
-typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) sp_u32x4 sp_lds_u32x4;
 
 struct SplitArgs {
   const float* A; long lda;
@@ -47,34 +40,6 @@ struct SplitArgs {
   const float* Y; long ldy;        // EPI 1: C = (A W) * act'(Y)
   double* colsum_ws;                // EPI 1: += column sums of C (replica layout of sbr_col_reduce, K = 1), may be null
 };
-
-__device__ __forceinline__ unsigned sp_pack(float x, float y) {     // two fp32 -> two bf16 (round to nearest even), x in the low half
-  sp_f32x2 v = {x, y};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sp_bf16x2));
-}
-
-// (x, y) -> three packed bf16 pairs with x = x0 + x1 + x2 exactly
-__device__ __forceinline__ void sp_split2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
-  p0 = sp_pack(x, y);
-  x -= __uint_as_float(p0 << 16);
-  y -= __uint_as_float(p0 & 0xffff0000u);
-  p1 = sp_pack(x, y);
-  x -= __uint_as_float(p1 << 16);
-  y -= __uint_as_float(p1 & 0xffff0000u);
-  p2 = sp_pack(x, y);
-}
-
-__device__ __forceinline__ void sp_split8(const float4 lo, const float4 hi, sp_u32x4& p0, sp_u32x4& p1, sp_u32x4& p2) {
-  unsigned a, b, c;
-  sp_split2(lo.x, lo.y, a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
-  sp_split2(lo.z, lo.w, a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
-  sp_split2(hi.x, hi.y, a, b, c); p0[2] = a; p1[2] = b; p2[2] = c;
-  sp_split2(hi.z, hi.w, a, b, c); p0[3] = a; p1[3] = b; p2[3] = c;
-}
-
-__device__ __forceinline__ sp_f32x16 sp_mfma(const sp_u32x4 a, const sp_u32x4 b, const sp_f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sp_bf16x8, a), __builtin_bit_cast(sp_bf16x8, b), c, 0, 0, 0);
-}
 
 // MODE 0: NT (W is [n][k]); MODE 1: NN (W is [k][n]). EPI 0: bias + activation; EPI 1: activation derivative of Y + column sums;
 // EPI 2 (MODE 0): EPI 0 + per-column sums and sums of squares of what is stored (the batch statistics of a BatchNorm that follows,
