@@ -22,7 +22,8 @@
 // chunk c is multiplied, chunk c + 1 is split and written into the other set and the raw values of chunks c + 2 .. c + 4 are in
 // flight (TS_NBUF = 3 raw buffers of 16 registers rotate; 4 measured slower); ONE barrier per chunk.  Waves 0-3 take k step 0 of every chunk, waves 4-7
 // k step 1; within a group each wave owns a 64 x 64 quarter of the tile (4 accumulator tiles, 12 fragment reads per 24 MFMAs).
-// The two groups' sums are added through LDS at the end in a fixed order and ONE slab per workgroup is stored: 256 slabs of 64 KB
+// The two groups' sums are added through LDS at the end in a fixed order and ONE slab per workgroup is stored (16 bytes per lane,
+// all eight waves): 256 slabs of 64 KB
 // for a 128 x 128 product, 42 x 6 for 128 x 768 — the ring kernel left 512 / 1536 partial tiles for the slab reducer.
 // Row pointers of the range (gathered or not; the pointer of a zero row past the end of K) are staged in LDS once.
 // Column blocks of the same K range run on the same XCD (its L2 then serves the re-reads of dZ).
@@ -221,27 +222,35 @@ _Pragma("unroll") \
     }
   }
 
-  // ---- the two k-step groups' sums through LDS (the plane sets are free: the last step ended with a barrier), one slab store
-  float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (64 * 64) + lane;
-  if (ks == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) red[(i * 16 + q) * 64] = acc[i][q];
-  }
-  __syncthreads();
-  if (ks == 0) {
+  // ---- epilogue: both k-step groups write their quarter tiles into a row-major 128 x 128 image each (the plane sets and the
+  // pointer lists are free: the last step ended with a barrier), then all 512 threads add the two images (fixed order) and store the
+  // slab with 16 bytes per lane, a 512-byte row per half wave.  (Stores straight from the accumulator layout — 8 bytes per lane, by
+  // half of the waves — are issue-bound: ~4 us for the 64 KB of a workgroup.)
+  {
+    float* img = reinterpret_cast<float*>(smem) + ks * (128 * 128);
     // accumulator (x, y), register q, lane: output row 64 mh + 2 (8 (q >> 2) + 4 half + (q & 3)) + x, column 64 nh + 2 l31 + y
-    float* out = g.slab + ((long)z * 128 + 64 * mh + 8 * half) * g.N + (long)j * 128 + 64 * nh + 2 * l31;
+    float* w = img + (64 * mh + 8 * half) * 128 + 64 * nh + 2 * l31;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         sp_f32x2 v;
-        v[0] = acc[x * 2][q] + red[((x * 2) * 16 + q) * 64];
-        v[1] = acc[x * 2 + 1][q] + red[((x * 2 + 1) * 16 + q) * 64];
-        *reinterpret_cast<sp_f32x2*>(out + (long)(2 * ((q & 3) + 8 * (q >> 2)) + x) * g.N) = v;
+        v[0] = acc[x * 2][q];
+        v[1] = acc[x * 2 + 1][q];
+        *reinterpret_cast<sp_f32x2*>(w + (2 * ((q & 3) + 8 * (q >> 2)) + x) * 128) = v;
       }
+  }
+  __syncthreads();
+  {
+    const float4* i0 = reinterpret_cast<const float4*>(smem);
+    const float4* i1 = i0 + 128 * 128 / 4;
+    float* out = g.slab + (long)z * 128 * g.N + (long)j * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = t + 512 * i;                                   // float4 f of the image: row f >> 5, columns 4 (f & 31) ..
+      const float4 a = i0[f], b = i1[f];
+      *reinterpret_cast<float4*>(out + (long)(f >> 5) * g.N + 4 * (f & 31)) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
   }
 }
 
@@ -268,7 +277,7 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
                         float* slab, int* splits_out, hipStream_t s) {
   const int nz = sbr_tn_split_splits(M, N, K);
   if (nz <= 0) return -1;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)slab) % 8 != 0 || lda % 2 != 0 || ldb % 2 != 0) return -1;
+  if (((uintptr_t)A | (uintptr_t)B) % 8 != 0 || (uintptr_t)slab % 16 != 0 || lda % 2 != 0 || ldb % 2 != 0) return -1;
   TnSplitArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.slab = slab; g.N = N; g.K = K;
   g.nz = nz; g.nj = N / 128; g.chunks = sbr_cdiv(K, TS_KC);

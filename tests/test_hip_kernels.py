@@ -545,6 +545,47 @@ def test_scatter_add_rows_sorted_is_the_dense_gradient_without_atomics(W, cap, D
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('n,n_table,skew,gather', [(4096, 5000, 0, False), (45824, 50000, 0, True), (8192, 100000, 0, False),
+                                                  (20000, 3000, 1, True), (9000, 40, 2, True), (131072, 70000, 1, False)])
+def test_scatter_add_rows_owner_kernel_is_the_dense_gradient_without_atomics(n, n_table, skew, gather, monkeypatch):
+    """The opt-in atomic-free form of sbr_scatter_add_rows (SBR_SCATTER_OWNED=1; D = 128 and 4,096 - 131,072 rows; csrc/rowops.hip
+    scatter_add_rows_owned_kernel; measured slower than the atomic kernel, kept as a recorded experiment): every workgroup
+    owns the table rows r mod 256 = its index, adds the gradient rows of a table row in slot order with plain stores — equal to
+    index_add in float64, the same bits on a second run, equal to the product's atomic kernel (SBR_SCATTER_OWNED=0) up to rounding; uniform
+    rows, popularity-skewed rows (one row drawn thousands of times: the per-wave list capacity overflows into the atomic tail),
+    a tiny table (every entry of a wave's scan is owned by few workgroups), an indexed source (in_idx) and a plain one."""
+    from importlib import import_module
+    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    D = 128
+    g = torch.Generator().manual_seed(n + skew)
+    n_src = n + 100
+    grads = torch.randn(n_src, D, generator=g)
+    if skew == 0:
+        rows = torch.randint(0, n_table, (n,), generator=g, dtype=torch.int32)
+    elif skew == 1:
+        rows = (torch.rand(n, generator=g) ** 6 * n_table).to(torch.int32).clamp_(max=n_table - 1)      # row 0 thousands of times
+    else:
+        rows = torch.randint(0, n_table, (n,), generator=g, dtype=torch.int32)
+    in_idx = torch.randperm(n_src, generator=g)[:n].to(torch.int32) if gather else None
+    src = grads[in_idx.long()] if gather else grads[:n]
+    ref = torch.full((n_table, D), 0.25, dtype=torch.float64)
+    ref.index_add_(0, rows.long(), src.double())
+    mag = torch.full((n_table, D), 0.25, dtype=torch.float64)
+    mag.index_add_(0, rows.long(), src.double().abs())
+    gd, rd = grads.to(DEV), rows.to(DEV)
+    idd = in_idx.to(DEV) if gather else None
+    outs = {}
+    for flag in ('1', '1', '0'):
+        monkeypatch.setenv('SBR_SCATTER_OWNED', flag)
+        dW = torch.full((n_table, D), 0.25, device=DEV)
+        _lib.call('sbr_scatter_add_rows', gd.data_ptr(), D, _lib.ptr(idd), rd.data_ptr(), dW.data_ptr(), D, n, D, _lib.stream())
+        outs.setdefault(flag, []).append(dW.double().cpu())
+    for o in outs['1'] + outs['0']:
+        assert bool(((o - ref).abs() <= 2.0 ** -20 * mag).all())
+    if skew != 1:                                              # no atomic tail: a fixed summation order
+        assert torch.equal(outs['1'][0], outs['1'][1])
+
+
 @pytest.mark.parametrize('name', ['adamw', 'adam'])
 def test_deferred_row_wise_adam_replay_is_bit_identical(name):
     """sbr_adam_rows (engine.DeferredTable): a lookup table whose rows take the optimizer steps they missed later, in order, with
