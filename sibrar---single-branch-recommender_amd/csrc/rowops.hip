@@ -433,8 +433,10 @@ extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_i
   if (D == 128 && n >= 4096 && n <= 131072 && ldo % 2 == 0 && ldw % 2 == 0 && ((uintptr_t)dOut | (uintptr_t)dW) % 8 == 0 &&
       getenv("SBR_SCATTER_OWNED") && atoi(getenv("SBR_SCATTER_OWNED")) == 1) {
     // OPT-IN experiment (correct, deterministic, measured slower): on uniformly drawn rows 25.8 us against the atomic kernel's
-    // 23.5 us (45,824 x 128), on the training step's own rows — popular items are drawn hundreds of times per batch, so a few
-    // workgroups own long chains and overflow into the atomic tail — 227 us on average. The atomic kernel stays the product path.
+    // 23.5 us (45,824 x 128; 37 against 29 us with a cold table), and on the training step's own lists 227 us on average: a
+    // graph-mode step pads every modality's slot list with ~770 sentinel slots that all name ONE table row (zero gradient rows,
+    // engine._EntityRun.plan), i.e. one workgroup owns a chain of hundreds of entries and most of them overflow into its atomic
+    // tail. The atomic kernel stays the product path.
     scatter_add_rows_owned_kernel<<<256, 64 * SO_WAVES, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n);
     SBR_CHECK_LAUNCH("sbr_scatter_add_rows");
     return SBR_OK;
