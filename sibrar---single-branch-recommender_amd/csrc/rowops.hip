@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void scatter_add_rows128_kernel(const float* _
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (j0 + q < n) {                                          // wave-uniform
+      // (a gradient row of zeros adds nothing: a graph-mode step pads every slot list with ~770 sentinel slots that all name ONE
+      // table row and carry a zero gradient row, engine._EntityRun.plan — 1,540 atomic instructions on the same four lines)
+      if (j0 + q < n && __ballot(v[q][0] != 0.f || v[q][1] != 0.f) != 0) {          // wave-uniform
         atomicAdd(&dW[dst[q] * ldw + lane], v[q][0]);
         atomicAdd(&dW[dst[q] * ldw + 64 + lane], v[q][1]);
       }
