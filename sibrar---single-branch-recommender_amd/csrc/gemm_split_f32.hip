@@ -314,6 +314,23 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
   const int n_it = (n_blocks + nw - 1) / nw;
   const int KC = g.K / PJ_KC;
   constexpr int PL = 4 * 4 * 64 * 16;                            // bytes of one plane of a chunk
+  // Work items. A round hands out nw blocks of 32 rows: the first S = nw / 2 to waves 0-3 (one per SIMD), the rest to waves 4-7
+  // (the SIMD's second wave). The two waves of a SIMD share its matrix pipe, so a workgroup with blocks on waves 4-7 walks its
+  // K chunks at half the pace. When the last round has between S and 1.5 S blocks (the projector of the bench: 1,432 blocks, S =
+  // 1,024), the blocks beyond S are split by COLUMNS between two waves 4-7 of neighbouring SIMDs (64 output columns each, both
+  // read and split the same A rows): every SIMD then carries at most 1.5 blocks instead of 2.
+  const int S = gridDim.x * 4;
+  const int last_it = n_it - 1;
+  const int rem = n_blocks - last_it * nw;                       // blocks of the last round: 1 .. nw
+  const bool half_mode = rem > S && 2 * rem <= 3 * S;
+  const int hs = blockIdx.x * 4 + (wave & 3);                    // half item of this wave (waves 4-7, last round, half mode)
+#define PJ_ITEM(it_, blk_, jlo_, jhi_, valid_) do { \
+    if ((it_) == last_it && half_mode && wave >= 4) { \
+      blk_ = last_it * nw + S + (hs >> 1); jlo_ = hs & 1; jhi_ = (hs & 1) + 1; valid_ = S + (hs >> 1) < rem; \
+    } else { \
+      blk_ = gw + (it_) * nw; jlo_ = 0; jhi_ = 2; valid_ = blk_ < n_blocks; \
+    } \
+  } while (0)
 
   // raw weight values of one chunk. A wave-instruction handles ONE operand fragment (column tile j, k step ks): lane L reads the
   // 8 values W(32 j + (L & 31), 16 ks + 8 (L >> 5) .. + 7) and, after the split, writes its 16 bytes at lane position L of the
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
   }
   sp_f32x16 acc[4];
   float4 r0[4][2], r1[4][2], r2[4][2];                           // three chunks of A rotate: two are in flight while one is multiplied
-  auto mult_chunk = [&](int buf, const float4 (&raw)[4][2]) __attribute__((always_inline)) {
+  auto mult_chunk = [&](int buf, const float4 (&raw)[4][2], int jlo, int jhi) __attribute__((always_inline)) {
     const unsigned char* wfrag = smem + buf * PJ_BUF + lane * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -372,6 +389,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
       sp_split8(raw[s][0], raw[s][1], a0, a1, a2);
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
+        if (jp < jlo || jp >= jhi) continue;                       // wave-uniform: a half item multiplies one pair of column tiles
         sp_u32x4 w[2][3];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -403,7 +421,12 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
   const float* ap0 = nullptr;                                    // row pointers of the wave's blocks with even / odd `it`
   const float* ap1 = nullptr;
   load_w(0);
-  if (gw < n_blocks) { ap0 = row_ptr(gw); load_chunk(ap0, 0, r0); load_chunk(ap0, 1, r1); }
+  {
+    int blk0, jl0, jh0;
+    bool v0;
+    PJ_ITEM(0, blk0, jl0, jh0, v0);
+    if (v0) { ap0 = row_ptr(blk0); load_chunk(ap0, 0, r0); load_chunk(ap0, 1, r1); }
+  }
   store_w(0);
   if (n_steps > 1) load_w(1 % KC);
   __syncthreads();
@@ -412,8 +435,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
     const int c = (CC); \
     if (c >= n_steps) break; \
     const int it = c / KC, kc = c - it * KC; \
-    const int blk = gw + it * nw; \
-    const bool valid = blk < n_blocks; \
+    int blk, jlo, jhi; \
+    bool valid; \
+    PJ_ITEM(it, blk, jlo, jhi, valid); \
     if (kc == 0) { \
 _Pragma("unroll") \
       for (int j = 0; j < 4; ++j) \
@@ -423,12 +447,14 @@ _Pragma("unroll") \
     if (valid) { \
  \
       const int c2 = c + 2, it2 = c2 / KC, kc2 = c2 - it2 * KC; \
-      const int blk2 = gw + it2 * nw; \
-      if (PJ_ABL != 3 && PJ_ABL != 4 && c2 < n_steps && blk2 < n_blocks) { \
+      int blk2, jlo2, jhi2; \
+      bool valid2; \
+      PJ_ITEM(it2, blk2, jlo2, jhi2, valid2); \
+      if (PJ_ABL != 3 && PJ_ABL != 4 && c2 < n_steps && valid2) { \
         if (kc2 == 0) { if (it2 & 1) ap1 = row_ptr(blk2); else ap0 = row_ptr(blk2); } \
         load_chunk((it2 & 1) ? ap1 : ap0, kc2, fill); \
       } \
-      mult_chunk(c & 1, cur); \
+      mult_chunk(c & 1, cur, jlo, jhi); \
     } \
     if (PJ_ABL != 2 && PJ_ABL != 4 && c + 1 < n_steps) { \
       store_w((c + 1) & 1); \
@@ -447,6 +473,7 @@ _Pragma("unroll") \
       } \
 _Pragma("unroll") \
       for (int j = 0; j < 4; ++j) { \
+        if ((j >> 1) < jlo || (j >> 1) >= jhi) continue; \
 _Pragma("unroll") \
         for (int r = 0; r < 16; ++r) { \
           const int lr = (r & 3) + 8 * (r >> 2); \
@@ -479,8 +506,8 @@ extern "C" int sbr_gemm_split_proj_f32(const float* A, long lda, const int* a_id
   ProjArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.c_idx = c_idx; g.M = M; g.K = K; g.act = act;
   const int n_blocks = sbr_cdiv(M, 32);
-  int grid = sbr_cdiv(n_blocks, SP_WAVES);
-  if (grid > 256) grid = 256;
+  int grid = sbr_cdiv(n_blocks, 4);                              // one block per SIMD first: the second wave of a SIMD only adds
+  if (grid > 256) grid = 256;                                    // matrix-pipe time to it (see the work-item note in the kernel)
   const size_t lds = 2 * PJ_BUF;
   static bool attr_set = false;
   if (!attr_set) {

@@ -412,6 +412,21 @@ class _EntityRun:
             br.join()
 
 
+_IDENTITY_SLOTS = {}
+
+
+def _identity_slots(n: int, device) -> torch.Tensor:
+    """0 .. n-1 as int32 on ``device``, built once per (n, device): a read-only constant of every step (a torch.arange per step is a
+    5 us launch inside the captured step)."""
+    key = (n, str(device))
+    t = _IDENTITY_SLOTS.get(key)
+    if t is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return torch.arange(n, device=device, dtype=torch.int32)       # never allocate a cached constant inside a capture
+        t = _IDENTITY_SLOTS[key] = torch.arange(n, device=device, dtype=torch.int32)
+    return t
+
+
 class _PlainRun:
     """Forward / backward of a plain FeatureEmbedding side (embedding lookup or projector on one feature)."""
 
@@ -430,7 +445,7 @@ class _PlainRun:
         flat = idx.reshape(-1)
         n = flat.numel()
         self.n = n
-        self.slots = torch.arange(n, device=flat.device, dtype=torch.int32)
+        self.slots = _identity_slots(n, flat.device)
         self.rows, _ = resolve_rows(flat, 1, self.slots, [0, n], [fe._table], fe._idx_err)
         self.out = a.f32(n, fe.front_dim)
         self.hidden = fe.front_forward(fe.front_params(), self.rows, n, self.out, None)

@@ -746,11 +746,13 @@ def test_split_gemm_has_the_error_of_the_fp32_pipe(M, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M,K', [(4096, 768), (5000, 256), (9001, 1024)])
+@pytest.mark.parametrize('M,K', [(4096, 768), (5000, 256), (9001, 1024), (45801, 256), (36000, 256), (52000, 256), (70001, 256)])
 def test_split_projector_gemm_has_the_error_of_the_fp32_pipe(M, K, monkeypatch):
     """sbr_gemm_split_proj_f32 (the dense modality projector on the bf16 matrix pipe: K walked in chunks of 128, row gather and row
     scatter fused) against an fp64 product, next to the fp32-pipe kernel on the same call: gathered rows with repeats, scattered
-    output rows, bias + the three activation kinds, a ragged last block; operands span six decades."""
+    output rows, bias + the three activation kinds, a ragged last block; operands span six decades. The long shapes cover the
+    work-item map on 256 workgroups: a last round whose blocks beyond one per SIMD are split by columns between two waves (1,432
+    and 1,125 blocks), one that fills both waves of the SIMDs (1,625), and two rounds (2,188)."""
     ops = S().ops
     monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
     g = torch.Generator().manual_seed(5)
