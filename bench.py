@@ -159,20 +159,34 @@ def gemm_table(timings, steps):
         _, mode, M, N, K, gathered = key
         avg_ms = sum(ts) / len(ts)
         tf = 2.0 * M * N * K / (avg_ms * 1e-3) / 1e12
+        sym, _what, terms, pipe = gemm_kernel(mode, M, N, K, gathered)
         rows.append({'kernel': f'{["NT", "NN", "TN"][mode]} M={M} N={N} K={K}' + (' gathered' if gathered else ''),
+                     'served_by': sym.strip().rstrip(',') + (' (bf16 pipe, 6 terms)' if pipe == 'bf16' else ' (fp32 pipe)'),
                      'launches_per_step': round(len(ts) / steps, 2), 'avg_launch_ms': round(avg_ms, 4),
                      'ms_per_step': round(sum(ts) / steps, 4), 'tflops': round(tf, 2), 'frac': round(tf / PEAK_MFMA_F32, 4)})
     return sorted(rows, key=lambda r: -r['ms_per_step'])
 
 
-# GEMM signature of the c2 step at B = 8192 -> (kernel template, grid threads) of its dispatches in the rocprofv3 PMC passes
-# (profiles/r01_bench_hbm_traffic.csv: FETCH_SIZE / WRITE_SIZE collected in their own runs, gfx950 correction applied by
-# tools/make_profiles.py). PMC counters cannot be read inside this process; `traffic` quotes that committed measurement.
-PMC_ROWS = {('TN', 128, 768): ('void gemm_ring_kernel<1, true, true, 2>', 196608),
-            ('TN', 128, 128): ('void gemm_ring_kernel<1, true, true, 2>', 131072),
-            ('NT', 128, 768): ('void gemm_ring_kernel<1, false, false, 2>', 183296),
-            ('NN', 128, 128): ('void gemm_ring_kernel<2, false, true, 2>', 131072),
-            ('NT', 128, 128): ('void gemm_ring_kernel<2, false, false, 2>', 131072)}
+def gemm_kernel(mode, M, N, K, gathered):
+    """-> (kernel symbol as the kernel trace names it, what it is, MFMA terms per fp32 multiply-add, pipe) of the launch that serves
+    this GEMM signature — the same decisions as ops.linear_nt / matmul_nn / matmul_tn and csrc/gemm_f32.hip take."""
+    import importlib
+    ops = importlib.import_module('sibrar_amd').ops
+    lib = importlib.import_module(ops.__name__.rsplit('.', 1)[0] + '._lib').lib()
+    env = os.environ
+    split = bool(getattr(ops, '_SPLIT', False))
+    if mode == 2:
+        on = split and env.get('SBR_TN_SPLIT', '1') != '0' and M == 128 and N >= 128 and N % 128 == 0 and K >= 4096
+        if on:
+            return (f'void gemm_split_tn_kernel<{"true" if N > 128 else "false"}>', 'bf16-split dW kernel (csrc/gemm_split_tn_f32.hip)', 6, 'bf16')
+        return ('void gemm_ring_kernel<1, true, true, 2>', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
+    rows = M
+    if split and rows >= getattr(ops, '_SPLIT_MIN_ROWS', 4096):
+        if mode == 0 and gathered and lib.sbr_gemm_split_proj_supported(int(M), int(N), int(K)):
+            return ('gemm_split_proj_kernel', 'bf16-split projector kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
+        if lib.sbr_gemm_split_supported(int(M), int(N), int(K)):
+            return (f'void gemm_split_kernel<{mode}, ', 'bf16-split K = N = 128 kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
+    return ('void gemm_ring_kernel<', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
 
 
 PMC_SCORER_PREFIX = '_Z23score_topk_f16_n_kernel'        # fused scorer dispatches in the same PMC passes (the only launches of that kernel there)
@@ -193,19 +207,22 @@ def _pmc_rows():
     return os.path.relpath(path, ROOT), list(csv.reader(l for l in open(path) if not l.startswith('#')))
 
 
-def pmc_traffic(mode, M, N, K, batch):
-    """HBM bytes per launch of a GEMM signature from the committed PMC summary (None when the run is not the profiled shape)."""
+def pmc_traffic(mode, M, N, K, batch, gathered=False):
+    """HBM bytes per launch of a GEMM signature from the committed PMC summary (None when the run is not the profiled shape, or when
+    the summary predates the kernel that serves the signature now)."""
     if batch != 8192:
         return None, None
-    key = {0: ('NT', N, K), 1: ('NN', N, K), 2: ('TN', M, N)}[mode]
-    row = PMC_ROWS.get(key)
+    sym = gemm_kernel(mode, M, N, K, gathered)[0]
     path, rows = _pmc_rows()
-    if row is None or path is None:
+    if path is None:
         return None, None
-    for r in rows:
-        if r[0] == row[0] and r[1] == str(row[1]):
-            return float(r[5]) * 1e6, path
-    return None, None
+    hit = [(float(r[2]), float(r[5])) for r in rows if len(r) >= 6 and r[0].startswith(sym)]
+    if sym.startswith('void gemm_ring_kernel<1, true') and len(hit) > 1:
+        return None, None                          # two TN shapes behind one ring symbol: not attributable
+    n = sum(h[0] for h in hit)
+    if not hit or n == 0:
+        return None, None
+    return sum(h[0] * h[1] for h in hit) / n * 1e6, path
 
 
 def pmc_scorer_traffic(n_users):
@@ -246,19 +263,29 @@ def dominant_gemm(timings, steps, batch=None):
         avg_ms += reduce_ms
     flops = 2.0 * M * N * K
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(mode, M, N, K, batch)
-    return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': traffic,
-            'traffic_source': None if traffic is None else f'HBM bytes per launch from {src} (rocprofv3 --pmc FETCH_SIZE and --pmc '
-                              f'WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
-            'kernel': f'fp32 MFMA GEMM (gemm_ring_kernel) mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
-                      + (f' + its share ({reduce_ms * 1e3:.1f} us, by slab bytes) of the step\'s shared split-K slab reduction '
-                         f'(splitk_reduce_multi_kernel)' if mode == 2 else ''),
+    traffic, src = pmc_traffic(mode, M, N, K, batch, gathered)
+    sym, what, terms, pipe = gemm_kernel(mode, M, N, K, gathered)
+    out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+           'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': traffic,
+           'traffic_source': None if traffic is None else f'HBM bytes per launch from {src} (rocprofv3 --pmc FETCH_SIZE and --pmc '
+                             f'WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
+           'kernel': f'{what}: {sym.strip()}, mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
+                     + (f' + its share ({reduce_ms * 1e3:.1f} us, by slab bytes) of the step\'s shared split-K slab reduction '
+                        f'(splitk_reduce_multi_kernel)' if mode == 2 else ''),
+           'pricing': 'achieved = algorithmic fp32 FLOP (2 M N K) / launch time, peak = the fp32 MFMA peak (the arithmetic the path '
+                      'computes in is fp32: `dtype`)'}
+    if pipe == 'bf16':
+        # the product is computed exactly enough for fp32 by SIX bf16 MFMA terms per multiply-add (three-way exact operand split):
+        # on the pipe it actually runs on the kernel issues 6 x the algorithmic FLOP
+        out['pipe'] = {'name': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 terms per fp32 multiply-add', 'achieved': round(achieved * terms, 1),
+                       'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s', 'frac': round(achieved * terms / PEAK_MFMA_F16, 4)}
+    out.update({
             'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps + reduce_ms * len(ts) / steps, 4),
             'timing': 'HIP events around every launch of this kernel over K plain-launch steps run right after the timed '
                       'region (the timed region replays a hipGraph, which cannot carry per-kernel events); each of those steps '
                       'is queued behind a spin kernel so that its kernels run back to back as they do in the replay',
-            'all_gemms': gemm_table(timings, steps)}
+            'all_gemms': gemm_table(timings, steps)})
+    return out
 
 
 def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):

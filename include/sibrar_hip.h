@@ -275,6 +275,14 @@ int sbr_rec_loss_bwd(int kind, const float* logits, const double* labels, long B
 /* both in one pass with upstream gradient 1 (the training step: total.backward() of train/trainer.py:213-221) */
 int sbr_rec_loss_fwd_bwd(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
                          double* loss_out, float* dlogits, void* stream);
+/* the same in ONE launch (new: the fused training step; sbr_rec_loss_fwd_bwd zeroes loss_out with a launch of its own and sums the
+ * block partial sums with double atomics): the partial sums go through ws — sbr_rec_loss_workspace(B) bytes, zeroed ONCE by the
+ * caller, left zeroed by every call; calls sharing a workspace must not overlap — and are added in block order (the same bits on
+ * every run). out3 (may be NULL): also writes (loss, loss, 0), the packed (total, rec, reg) scalars of a step without
+ * regularisation losses (what sbr_pack_losses would produce). B >= 1. */
+long sbr_rec_loss_workspace(long B);
+int sbr_rec_loss_fwd_bwd_ws(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                            double* loss_out, float* dlogits, double* out3, void* ws, long ws_bytes, void* stream);
 
 /* InfoNCE.forward — train/regularization_losses.py:14-43, called from algorithms/sgd_alg.py:1989 on e[..., 0, :] and
  * e[..., 1, :]. G groups of N rows, row stride ld; N <= sbr_infonce_max_n(). scale = 1/(G*N) for 'mean'. */

@@ -54,6 +54,9 @@ struct TnSplitArgs {
 __device__ __attribute__((aligned(256))) float ts_zero_row[128];
 typedef const __attribute__((address_space(1))) sp_f32x2* ts_gptr;      // row pointers come back from LDS as integers: say that they are global
 
+// WIDE: N > 128 (several column blocks per K range). The two forms differ only in the workgroup map — and in their symbol, which
+// keeps the step's 128 x 128 and 128 x 768 products apart in a kernel trace.
+template <bool WIDE>
 __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   const int W = gridDim.x;                                         // a multiple of 8
   const int L = (blockIdx.x & 7) * (W >> 3) + (blockIdx.x >> 3);
   if (L >= g.nz * g.nj) return;
-  const int z = L / g.nj, j = L - z * g.nj;
+  const int z = WIDE ? L / g.nj : L, j = WIDE ? L - z * g.nj : 0;
   const int cb = g.chunks / g.nz, cr = g.chunks - cb * g.nz;
   const int c_begin = z * cb + (z < cr ? z : cr);
   const int n_chunks = cb + (z < cr ? 1 : 0);                      // >= 1 (host: nz <= chunks), <= TS_MAXROWS / 32 - TS_PAD
@@ -282,16 +285,22 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.slab = slab; g.N = N; g.K = K;
   g.nz = nz; g.nj = N / 128; g.chunks = sbr_cdiv(K, TS_KC);
   const size_t lds = 2 * TS_BUF + 2 * TS_MAXROWS * sizeof(unsigned long long);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_split_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      sbr_set_error("sbr_gemm_tn_f32: cannot raise the dynamic LDS limit of the bf16-split kernel");
-      return SBR_ERR_HIP;
-    }
-    attr_set = true;
-  }
   const int grid = sbr_cdiv(nz * g.nj, 8) * 8;
-  gemm_split_tn_kernel<<<grid, 512, lds, s>>>(g);
+#define TS_LAUNCH(WIDE)                                                                                                   \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)gemm_split_tn_kernel<WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        sbr_set_error("sbr_gemm_tn_f32: cannot raise the dynamic LDS limit of the bf16-split kernel");                     \
+        return SBR_ERR_HIP;                                                                                                \
+      }                                                                                                                    \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    gemm_split_tn_kernel<WIDE><<<grid, 512, lds, s>>>(g);                                                                  \
+  } while (0)
+  if (g.nj > 1) TS_LAUNCH(true);
+  else TS_LAUNCH(false);
+#undef TS_LAUNCH
   SBR_CHECK_LAUNCH("sbr_gemm_tn_f32 (bf16 split)");
   *splits_out = nz;
   return SBR_OK;

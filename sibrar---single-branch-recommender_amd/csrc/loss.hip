@@ -31,10 +31,14 @@ __device__ __forceinline__ double bce_term(double x, double y) { return fmax(x, 
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // one thread per batch row
-template <int MODE>   // 0: loss, 1: gradient, 2: both (upstream gradient 1: the fused training step)
+// MODE 3 = MODE 2 without a zeroed loss_out: every block leaves its partial sum in ws[1 + block], the block whose agent-scope
+// counter add (ws[0]) comes last sums the partials in block order (the same bits on every run), writes loss_out (and out3 =
+// (loss, loss, 0) when given: the packed total / rec / reg scalars of a step without regularisation losses) and resets the counter.
+template <int MODE>   // 0: loss, 1: gradient, 2: both (upstream gradient 1: the fused training step), 3: both, self-contained sum
 __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, const double* __restrict__ labels, long B, int N,
                                 double scale, float shift, double* __restrict__ loss_out, const void* __restrict__ gout,
-                                int gout_is_double, float* __restrict__ dlogits) {
+                                int gout_is_double, float* __restrict__ dlogits, double* __restrict__ ws = nullptr,
+                                double* __restrict__ out3 = nullptr) {
   const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
   double acc = 0.0;
   constexpr bool FWD = MODE != 1, BWD = MODE != 0;
@@ -81,7 +85,23 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
   if (FWD) {
     __shared__ double sm[4];
     const double t = block_sum_d(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
+    if (MODE == 3) {
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&ws[1 + blockIdx.x], t * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull);
+        if (before == gridDim.x - 1) {                           // every other block's partial is out
+          __threadfence();
+          double sum = 0.0;
+          for (unsigned i = 0; i < gridDim.x; ++i) sum += __hip_atomic_load(&ws[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          loss_out[0] = sum;
+          if (out3) { out3[0] = sum; out3[1] = sum; out3[2] = 0.0; }
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(ws), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    } else if (threadIdx.x == 0) {
+      atomicAdd(loss_out, t * scale);
+    }
   }
 }
 
@@ -119,6 +139,24 @@ extern "C" int sbr_rec_loss_fwd_bwd(int kind, const float* logits, const double*
   if (B == 0) return SBR_OK;
   rec_loss_kernel<2><<<sbr_cdiv(B, 256), 256, 0, s>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0, dlogits);
   SBR_CHECK_LAUNCH("sbr_rec_loss_fwd_bwd");
+  return SBR_OK;
+}
+
+// The same with ONE launch: no zeroing launch in front (the block partial sums go through ``ws``, sbr_rec_loss_workspace(B) bytes that
+// the caller zeroes ONCE and then leaves alone: the kernel resets what it uses), a fixed summation order, and optionally the packed
+// loss scalars out3 = (loss, loss, 0) of a step without regularisation losses (what sbr_pack_losses would write). Calls that share a
+// workspace must not overlap in time.
+extern "C" long sbr_rec_loss_workspace(long B) { return (sbr_cdiv(B > 0 ? B : 1, 256) + 1) * (long)sizeof(double); }
+
+extern "C" int sbr_rec_loss_fwd_bwd_ws(int kind, const float* logits, const double* labels, long B, int N, double scale, float shift,
+                                       double* loss_out, float* dlogits, double* out3, void* ws, long ws_bytes, void* stream) {
+  SBR_REQUIRE(kind >= 0 && kind <= 2, "sbr_rec_loss_fwd_bwd_ws: unknown loss kind %d", kind);
+  SBR_REQUIRE(logits && loss_out && dlogits && (kind == LOSS_SSM || labels), "sbr_rec_loss_fwd_bwd_ws: null operand");
+  SBR_REQUIRE(B >= 1, "sbr_rec_loss_fwd_bwd_ws: empty batch (use sbr_rec_loss_fwd_bwd)");
+  SBR_REQUIRE(ws && ws_bytes >= sbr_rec_loss_workspace(B), "sbr_rec_loss_fwd_bwd_ws: workspace too small");
+  rec_loss_kernel<3><<<sbr_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(kind, logits, labels, B, N, scale, shift, loss_out, nullptr, 0,
+                                                                           dlogits, (double*)ws, out3);
+  SBR_CHECK_LAUNCH("sbr_rec_loss_fwd_bwd_ws");
   return SBR_OK;
 }
 

@@ -559,6 +559,8 @@ class FusedTrainStep:
         self.n_replays = 0
         self._up_stream = None
         self._label_cache = {}
+        self._loss_ws = None         # partial sums + arrival counter of the one-launch loss kernel (zeroed once, self-resetting)
+        self._packed = None
         # two-phase launch (and two graphs) when gradients are exchanged: see _reduce_user_part. SBR_FORCE_SPLIT=1 exercises
         # the same launch structure on one GPU.
         self.split = parallel.is_distributed() or os.environ.get('SBR_FORCE_SPLIT', '0') == '1'
@@ -634,7 +636,20 @@ class FusedTrainStep:
         shift = math.log(rl.n_items / rl.neg_train) if (self.kind == 2 and rl.train_neg_strategy == 'uniform') else 0.0
         loss = a.f64()
         dlog = a.f32(B, N)
-        call('sbr_rec_loss_fwd_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog), st)
+        self._packed = None
+        if self.user.reg_loss is None and self.item.reg_loss is None and B >= 1 and os.environ.get('SBR_LOSS_WS', '1') != '0':
+            # one launch: no zeroing launch in front, block partial sums added in a fixed order, and the packed (total, rec, reg)
+            # scalars of the step written by the same kernel (no regularisation losses: total = rec)
+            need = int(ops.lib().sbr_rec_loss_workspace(B))
+            if self._loss_ws is None or self._loss_ws.numel() * 8 < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('the loss workspace must exist before a step is captured (run one plain step first)')
+                self._loss_ws = torch.zeros((need + 7) // 8, device=logits.device, dtype=torch.float64)
+            self._packed = a.f64(3)
+            call('sbr_rec_loss_fwd_bwd_ws', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog),
+                 ptr(self._packed), ptr(self._loss_ws), self._loss_ws.numel() * 8, st)
+        else:
+            call('sbr_rec_loss_fwd_bwd', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog), st)
         dU = a.f32(B, D)
         if tail is not None:
             # dU and the BatchNorm column sums in one pass over the pre-BatchNorm rows; the item gradient dlog[s] * u[b] is
@@ -655,6 +670,8 @@ class FusedTrainStep:
         a, st = self.arena, ops.stream()
         dI, loss, tail = self._p2
         self.item.backward(dI, self.one32, tail)
+        if self._packed is not None:
+            return self._packed
         out = a.f64(3)                                               # (total, rec, reg)
         ru, ri = self.user.reg_loss, self.item.reg_loss
         call('sbr_pack_losses', ptr(loss), ptr(ru), float(getattr(self.user, 'reg_w', 0.0)), ptr(ri),

@@ -193,6 +193,39 @@ def test_rec_losses_vs_oracle(kind, agg, B, N):
         close(ld.grad.cpu(), lr.grad, rtol=1e-4, atol=1e-7, what='dlogits', norm_rtol=1e-5)
 
 
+@pytest.mark.parametrize('kind', [0, 1, 2])
+@pytest.mark.parametrize('B,N', [(1, 2), (300, 11), (8192, 11), (100000, 3)])
+def test_rec_loss_one_launch_entry_point(kind, B, N):
+    """sbr_rec_loss_fwd_bwd_ws (the fused step's loss: no zeroing launch, block partial sums through a self-resetting workspace,
+    fixed summation order, packed (total, rec, reg) scalars) against sbr_rec_loss_fwd_bwd (itself pinned against the oracle above):
+    same gradient bits, loss equal to rounding, the same loss bits on repeated calls, a dirty loss_out, and the workspace left zeroed."""
+    from importlib import import_module
+    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    logits = (_rand(B, N, seed=44) * 3).to(DEV)
+    labels = torch.zeros(B, N, dtype=torch.float64)
+    labels[:, 0] = 1
+    labels = labels.to(DEV)
+    scale, shift = 1.0 / B, 0.37 if kind == 2 else 0.0
+    l0, g0 = torch.full((1,), 7.0, device=DEV, dtype=torch.float64), torch.empty(B, N, device=DEV)
+    _lib.call('sbr_rec_loss_fwd_bwd', kind, logits.data_ptr(), labels.data_ptr(), B, N, scale, shift, l0.data_ptr(), g0.data_ptr(),
+              _lib.stream())
+    need = int(_lib.lib().sbr_rec_loss_workspace(B))
+    ws = torch.zeros(need // 8, device=DEV, dtype=torch.float64)
+    seen = []
+    for rep in range(3):
+        l1, g1 = torch.full((1,), -3.0 * rep, device=DEV, dtype=torch.float64), torch.empty(B, N, device=DEV)
+        out3 = torch.full((3,), 9.0, device=DEV, dtype=torch.float64)
+        _lib.call('sbr_rec_loss_fwd_bwd_ws', kind, logits.data_ptr(), labels.data_ptr(), B, N, scale, shift, l1.data_ptr(),
+                  g1.data_ptr(), out3.data_ptr() if rep != 1 else None, ws.data_ptr(), need, _lib.stream())
+        assert torch.equal(g1, g0)
+        assert abs(l1.item() - l0.item()) <= 1e-12 * abs(l0.item()) + 1e-15
+        if rep != 1:
+            assert out3.cpu().tolist() == [l1.item(), l1.item(), 0.0]
+        assert ws.view(torch.int64)[0].item() == 0              # the arrival counter is reset
+        seen.append(l1.item())
+    assert seen[0] == seen[1] == seen[2]
+
+
 @pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8), (64, 40, 16), (1, 256, 64), (2, 300, 30),
                                    (1, 1000, 128)])
 def test_infonce_vs_oracle(G, N, D):
