@@ -32,6 +32,12 @@
 #ifndef TS_ABL
 #define TS_ABL 0                  // lab (timing only): 1 no global loads in the loop, 2 no split / plane stores in the loop, 3 = 1 + 2, 4 no loop at all (set-up, prologue and epilogue only)
 #endif
+#ifndef TS_SALU
+#define TS_SALU 0                 // 0: row pointer lists staged in LDS; 1 (experiment, measured SLOWER: 29.8 / 73.5 us against 26.4 / 64.4 us on the
+                                  // same box): row pointers by SALU arithmetic + scalar index loads one step ahead — the set-up loses its
+                                  // memory round trip (7.6 instead of 8.7 us without any chunk), but the scalar loads share lgkmcnt with the
+                                  // LDS traffic: every fragment / barrier wait of the next step also waits for them
+#endif
 #define TS_KC 32                  // rows per chunk
 #define TS_PL (4 * 2 * 64 * 16)   // one bf16 plane of one operand of a chunk: [4 tiles of 32 columns][2 k steps][64 lanes][16 B] = 8 KB
 #define TS_OP (3 * TS_PL)         // the three planes of an operand
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   const int n_chunks = cb + (z < cr ? 1 : 0);                      // >= 1 (host: nz <= chunks), <= TS_MAXROWS / 32 - TS_PAD
   const long row0 = (long)c_begin * TS_KC;
 
+#if !TS_SALU
   // ---- row pointers of the range (operand B: of column block j), the zero row for rows past the end
   unsigned long long* ptrs = reinterpret_cast<unsigned long long*>(smem + 2 * TS_BUF);            // [2][TS_MAXROWS]
   {
@@ -104,15 +111,60 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
     }
   }
   __syncthreads();
+#endif
 
   // ---- loader role: waves 0-3 operand A, waves 4-7 operand B; wave & 3 = the group of 8 rows of the chunk; a thread owns the
   // columns 2 lane and 2 lane + 1 of its operand's 128
   const int op = wave >> 2, rg = wave & 3;
-  const unsigned char* optr = smem + 2 * TS_BUF + (op * TS_MAXROWS + rg * 8) * 8;
   // destination of the split values: fragment (tile = half [+ 2 for the odd column], k step = rg >> 1), lane position l31 + 32 (rg & 1)
   const int st_off = op * TS_OP + ((((half) * 2 + (rg >> 1)) * 64) + l31 + 32 * (rg & 1)) * 16;
 
   sp_f32x2 r0[8], r1[8], r2[8], r3[8];
+#if TS_SALU
+  // Row pointers without LDS or VALU: the wave's eight rows of a chunk are wave-uniform, so their pointers are SALU arithmetic on
+  // SGPRs — base + row * ld for a plain operand, base + idx[row] * ld with the indices of the NEXT chunk to request fetched by
+  // scalar loads one step ahead (through the constant address space: the index lists are read-only for the launch); rows past
+  // the end of the range or of K get the zero row (s_cselect). No pointer list is staged, the set-up needs no memory round trip.
+  typedef const __attribute__((address_space(4))) int* ts_cidx;
+  const float* obase = op ? g.B + (long)j * 128 : g.A;
+  const long old_ = op ? g.ldb : g.lda;
+  const int* gidx = op ? g.b_idx : g.a_idx;
+  const bool has_idx = gidx != nullptr;
+  typedef int ts_i8 __attribute__((ext_vector_type(8), aligned(4)));
+  typedef const __attribute__((address_space(4))) ts_i8* ts_cidx8;
+  const ts_cidx sidx = (ts_cidx)gidx + row0;                        // first entry of the range in the index list
+  const long rows_left = (long)g.K - row0;
+  const int valid_rows = (int)(rows_left < (long)n_chunks * TS_KC ? rows_left : (long)n_chunks * TS_KC);      // >= 1
+  int nid[8];
+  // the eight table rows of the wave's row group of chunk C: one s_load_dwordx8 (a group that reaches past the end of the range:
+  // clamped single loads — the last chunk of the last range only; plain operands: the row numbers themselves)
+#define TS_IDX(C, ids) do { \
+    const int r0_ = (C) * TS_KC + rg * 8; \
+    if (!has_idx) { \
+_Pragma("unroll") \
+      for (int q_ = 0; q_ < 8; ++q_) ids[q_] = (int)row0 + r0_ + q_; \
+    } else if (r0_ + 8 <= valid_rows) { \
+      const ts_i8 v_ = *(ts_cidx8)(sidx + r0_); \
+_Pragma("unroll") \
+      for (int q_ = 0; q_ < 8; ++q_) ids[q_] = v_[q_]; \
+    } else { \
+_Pragma("unroll") \
+      for (int q_ = 0; q_ < 8; ++q_) ids[q_] = sidx[r0_ + q_ < valid_rows ? r0_ + q_ : valid_rows - 1]; \
+    } \
+  } while (0)
+#define TS_LOADI(C, raw, ids) do { \
+_Pragma("unroll") \
+    for (int q_ = 0; q_ < 8; ++q_) { \
+      const int r_ = (C) * TS_KC + rg * 8 + q_; \
+      const bool in_ = r_ < valid_rows; \
+      const float* b_ = in_ ? obase : (const float*)ts_zero_row; \
+      const long o_ = in_ ? (long)ids[q_] * old_ : 0; \
+      raw[q_] = ((ts_gptr)(b_ + o_))[lane]; \
+    } \
+  } while (0)
+#define TS_LOAD(C, raw) do { TS_LOADI(C, raw, nid); TS_IDX((C) + 1, nid); } while (0)
+#else
+  const unsigned char* optr = smem + 2 * TS_BUF + (op * TS_MAXROWS + rg * 8) * 8;
 #define TS_LOAD(C, raw) do { \
     const sp_lds_u32x4* ip_ = (const sp_lds_u32x4*)(optr + (C) * (TS_KC * 8)); \
     const sp_u32x4 v0_ = ip_[0], v1_ = ip_[1], v2_ = ip_[2], v3_ = ip_[3];      /* eight row pointers, the same for every lane */ \
@@ -124,6 +176,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
     raw[q] = pa_[lane]; \
     raw[q + 1] = pb_[lane]; \
   } while (0)
+#endif
 #define TS_STORE(buf, raw) do { \
 _Pragma("unroll") \
     for (int h_ = 0; h_ < 2; ++h_) { \
@@ -165,12 +218,26 @@ _Pragma("unroll") \
   } while (0)
 
   // ---- prologue: chunks 0 .. 3 in flight, chunk 0 split into set 0, chunk 4 requested
+#if TS_SALU
+  {
+    int i0[8], i1[8];                                              // two index chunks per round of scalar loads
+    TS_IDX(0, i0); TS_IDX(1, i1);
+    TS_LOADI(0, r0, i0);
+    TS_LOADI(1, r1, i1);
+    TS_IDX(2, i0); TS_IDX(3, i1);
+    TS_LOADI(2, r2, i0);
+    if (TS_NBUF == 4) { TS_LOADI(3, r3, i1); TS_IDX(4, nid); } else { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) nid[q_] = i1[q_]; }
+  }
+  TS_STORE(0, r0);
+  TS_LOAD(TS_NBUF, r0);
+#else
   TS_LOAD(0, r0);
   TS_LOAD(1, r1);
   TS_LOAD(2, r2);
   if (TS_NBUF == 4) TS_LOAD(3, r3);
   TS_STORE(0, r0);
   TS_LOAD(TS_NBUF, r0);
+#endif
   __syncthreads();
 
   // step c: multiply set c & 1; split chunk c + 1 (raw buffer (c + 1) % 4) into the other set; request chunk c + 5 into that buffer.
@@ -284,7 +351,7 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
   TnSplitArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.slab = slab; g.N = N; g.K = K;
   g.nz = nz; g.nj = N / 128; g.chunks = sbr_cdiv(K, TS_KC);
-  const size_t lds = 2 * TS_BUF + 2 * TS_MAXROWS * sizeof(unsigned long long);
+  const size_t lds = TS_SALU ? 2 * 128 * 128 * sizeof(float) : 2 * TS_BUF + 2 * TS_MAXROWS * sizeof(unsigned long long);   // TS_SALU: the epilogue images (128 KB)
   const int grid = sbr_cdiv(nz * g.nj, 8) * 8;
 #define TS_LAUNCH(WIDE)                                                                                                   \
   do {                                                                                                                     \
