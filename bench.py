@@ -176,9 +176,9 @@ def gemm_kernel(mode, M, N, K, gathered):
     env = os.environ
     split = bool(getattr(ops, '_SPLIT', False))
     if mode == 2:
-        on = split and env.get('SBR_TN_SPLIT', '1') != '0' and M == 128 and N >= 128 and N % 128 == 0 and K >= 4096
+        on = split and env.get('SBR_TN_SPLIT', '1') != '0' and M >= 128 and M % 128 == 0 and N >= 128 and N % 128 == 0 and K >= 4096
         if on:
-            return (f'void gemm_split_tn_kernel<{"true" if N > 128 else "false"}>', 'bf16-split dW kernel (csrc/gemm_split_tn_f32.hip)', 6, 'bf16')
+            return (f'void gemm_split_tn_kernel<{"true" if (N // 128) * (M // 128) > 1 else "false"}>', 'bf16-split dW kernel (csrc/gemm_split_tn_f32.hip)', 6, 'bf16')
         return ('void gemm_ring_kernel<1, true, true, 2>', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
     rows = M
     if split and rows >= getattr(ops, '_SPLIT_MIN_ROWS', 4096):

@@ -1,7 +1,8 @@
 // Weight-gradient products of the training step on the bf16 matrix pipe:
-//     slab[z][128][N] = sum over the rows r of K range z of  A[ak(r), 0..127]^T  B[bk(r), 0..N-1]
+//     slab[z][M][N] = sum over the rows r of K range z of  A[ak(r), 0..M-1]^T  B[bk(r), 0..N-1]
 // (autograd of nn.Linear w.r.t. its weight, modules/polylinear.py:51 and sgd_alg.py:1279-1396: dW = dZ^T X with dZ [R, 128] and
-// X [R, N], either operand gathered by row). M = 128, N a multiple of 128, the reduction runs over the ROWS of both operands ("TN").
+// X [R, N], either operand gathered by row). M and N multiples of 128 (M = 128 in the c2 step, 512 in c3), the reduction runs over
+// the ROWS of both operands ("TN").
 //
 // Arithmetic: as in gemm_split_f32.hip — both fp32 operands are split exactly into three bf16 numbers, the six leading partial
 // products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped terms are < 2^-23 of each product).  With
@@ -51,17 +52,17 @@
 struct TnSplitArgs {
   const float* A; long lda; const int* a_idx;
   const float* B; long ldb; const int* b_idx;
-  float* slab;                    // [nz][128][N]
-  int N, K;
-  int nz, nj;                     // K ranges, column blocks (N / 128)
+  float* slab;                    // [nz][M][N]
+  int M, N, K;
+  int nz, nj, nm;                 // K ranges, column blocks (N / 128), row blocks (M / 128)
   int chunks;                     // ceil(K / 32)
 };
 
 __device__ __attribute__((aligned(256))) float ts_zero_row[128];
 typedef const __attribute__((address_space(1))) sp_f32x2* ts_gptr;      // row pointers come back from LDS as integers: say that they are global
 
-// WIDE: N > 128 (several column blocks per K range). The two forms differ only in the workgroup map — and in their symbol, which
-// keeps the step's 128 x 128 and 128 x 768 products apart in a kernel trace.
+// WIDE: more than one 128 x 128 output tile per K range. The two forms differ only in the workgroup map — and in their symbol,
+// which keeps the step's 128 x 128 and 128 x 768 products apart in a kernel trace.
 template <bool WIDE>
 __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,8 +73,10 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   // workgroup -> (K range z, column block j): consecutive logical indices share z; the logical index is contiguous per XCD
   const int W = gridDim.x;                                         // a multiple of 8
   const int L = (blockIdx.x & 7) * (W >> 3) + (blockIdx.x >> 3);
-  if (L >= g.nz * g.nj) return;
-  const int z = WIDE ? L / g.nj : L, j = WIDE ? L - z * g.nj : 0;
+  const int tiles = WIDE ? g.nj * g.nm : 1;                        // 128 x 128 output tiles per K range: consecutive L share z
+  if (L >= g.nz * tiles) return;
+  const int z = WIDE ? L / tiles : L, tile = WIDE ? L - z * tiles : 0;
+  const int mi = WIDE ? tile / g.nj : 0, j = WIDE ? tile - mi * g.nj : 0;
   const int cb = g.chunks / g.nz, cr = g.chunks - cb * g.nz;
   const int c_begin = z * cb + (z < cr ? z : cr);
   const int n_chunks = cb + (z < cr ? 1 : 0);                      // >= 1 (host: nz <= chunks), <= TS_MAXROWS / 32 - TS_PAD
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
       const int r = t + 512 * q;
       const bool in = r < n_in && row0 + r < g.K;
       if (r < n_list) {
-        ptrs[r] = (unsigned long long)(in ? g.A + ra[q] * g.lda : ts_zero_row);
+        ptrs[r] = (unsigned long long)(in ? g.A + ra[q] * g.lda + (long)mi * 128 : ts_zero_row);
         ptrs[TS_MAXROWS + r] = (unsigned long long)(in ? g.B + rb[q] * g.ldb + (long)j * 128 : ts_zero_row);
       }
     }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
   // scalar loads one step ahead (through the constant address space: the index lists are read-only for the launch); rows past
   // the end of the range or of K get the zero row (s_cselect). No pointer list is staged, the set-up needs no memory round trip.
   typedef const __attribute__((address_space(4))) int* ts_cidx;
-  const float* obase = op ? g.B + (long)j * 128 : g.A;
+  const float* obase = op ? g.B + (long)j * 128 : g.A + (long)mi * 128;
   const long old_ = op ? g.ldb : g.lda;
   const int* gidx = op ? g.b_idx : g.a_idx;
   const bool has_idx = gidx != nullptr;
@@ -314,7 +317,7 @@ _Pragma("unroll") \
   {
     const float4* i0 = reinterpret_cast<const float4*>(smem);
     const float4* i1 = i0 + 128 * 128 / 4;
-    float* out = g.slab + (long)z * 128 * g.N + (long)j * 128;
+    float* out = g.slab + ((long)z * g.M + (long)mi * 128) * g.N + (long)j * 128;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int f = t + 512 * i;                                   // float4 f of the image: row f >> 5, columns 4 (f & 31) ..
@@ -332,8 +335,8 @@ static bool ts_enabled() {          // read per call: tests and A/B runs switch 
 
 // K ranges (= slabs) the kernel would write for this shape; 0: the shape stays on the fp32 pipe
 int sbr_tn_split_splits(int M, int N, int K) {
-  if (!ts_enabled() || M != 128 || N < 128 || N % 128 != 0 || K < 4096) return 0;      // (the launch also wants 8-byte aligned rows)
-  const int nj = N / 128, chunks = sbr_cdiv(K, TS_KC);
+  if (!ts_enabled() || M < 128 || M % 128 != 0 || N < 128 || N % 128 != 0 || K < 4096) return 0;      // (the launch also wants 8-byte aligned rows)
+  const int nj = (N / 128) * (M / 128), chunks = sbr_cdiv(K, TS_KC);                                    // output tiles per K range
   int nz = 256 / nj;
   const int least = sbr_cdiv(chunks, TS_MAXROWS / TS_KC - TS_PAD);
   if (nz < least) nz = least;
@@ -342,7 +345,7 @@ int sbr_tn_split_splits(int M, int N, int K) {
   return nz;
 }
 
-// slab[z][128][N] for z < sbr_tn_split_splits(M, N, K) (plain stores). Returns -1 when the shape is not eligible.
+// slab[z][M][N] for z < sbr_tn_split_splits(M, N, K) (plain stores). Returns -1 when the shape is not eligible.
 int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                         float* slab, int* splits_out, hipStream_t s) {
   const int nz = sbr_tn_split_splits(M, N, K);
@@ -350,9 +353,9 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
   if (((uintptr_t)A | (uintptr_t)B) % 8 != 0 || (uintptr_t)slab % 16 != 0 || lda % 2 != 0 || ldb % 2 != 0) return -1;
   TnSplitArgs g;
   g.A = A; g.lda = lda; g.a_idx = a_idx; g.B = B; g.ldb = ldb; g.b_idx = b_idx; g.slab = slab; g.N = N; g.K = K;
-  g.nz = nz; g.nj = N / 128; g.chunks = sbr_cdiv(K, TS_KC);
+  g.M = M; g.nz = nz; g.nj = N / 128; g.nm = M / 128; g.chunks = sbr_cdiv(K, TS_KC);
   const size_t lds = TS_SALU ? 2 * 128 * 128 * sizeof(float) : 2 * TS_BUF + 2 * TS_MAXROWS * sizeof(unsigned long long);   // TS_SALU: the epilogue images (128 KB)
-  const int grid = sbr_cdiv(nz * g.nj, 8) * 8;
+  const int grid = sbr_cdiv(nz * g.nj * g.nm, 8) * 8;
 #define TS_LAUNCH(WIDE)                                                                                                   \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
@@ -365,7 +368,7 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
     }                                                                                                                      \
     gemm_split_tn_kernel<WIDE><<<grid, 512, lds, s>>>(g);                                                                  \
   } while (0)
-  if (g.nj > 1) TS_LAUNCH(true);
+  if (g.nj * g.nm > 1) TS_LAUNCH(true);
   else TS_LAUNCH(false);
 #undef TS_LAUNCH
   SBR_CHECK_LAUNCH("sbr_gemm_tn_f32 (bf16 split)");

@@ -854,18 +854,19 @@ def test_direct_tn_kernel_matches_fp64_and_the_ring_kernel(N, K, gather, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,K,gather', [(128, 4096, ''), (128, 9001, ''), (128, 90112, 'a'), (768, 8200, 'b'), (256, 20011, 'ab'),
-                                        (768, 45824, 'b'), (128, 600000, '')])
-def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(N, K, gather, monkeypatch):
-    """sbr_gemm_tn_f32 on the weight-gradient shapes (M = 128, N = 128 j, K >= 4096 rows) runs on the bf16 matrix pipe
+@pytest.mark.parametrize('M,N,K,gather', [(128, 128, 4096, ''), (128, 128, 9001, ''), (128, 128, 90112, 'a'), (128, 768, 8200, 'b'),
+                                          (128, 256, 20011, 'ab'), (128, 768, 45824, 'b'), (128, 128, 600000, ''), (256, 128, 9001, 'b'),
+                                          (512, 512, 30011, 'a')])
+def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(M, N, K, gather, monkeypatch):
+    """sbr_gemm_tn_f32 on the weight-gradient shapes (M and N multiples of 128, K >= 4096 rows) runs on the bf16 matrix pipe
     (csrc/gemm_split_tn_f32.hip: exact three-way split of both operands, six MFMA terms): against an fp64 product, next to the
     fp32-pipe ring kernel (SBR_TN_SPLIT=0) on the same call — plain and row-gathered operands (either side), operands spanning six
-    decades, K ranges that end inside a 32-row chunk, more than one round of workgroups (K = 600,000), the deferred-slab path."""
+    decades, K ranges that end inside a 32-row chunk, more than one round of workgroups (K = 600,000; 512 x 512), the deferred-slab path."""
     ops = S().ops
     g = torch.Generator().manual_seed(19)
     n_src = 5000
-    scale_a = torch.logspace(-3, 3, 128).unsqueeze(0)
-    dz = (_rand(n_src if 'a' in gather else K, 128, seed=71) * scale_a).to(DEV)
+    scale_a = torch.logspace(-3, 3, M).unsqueeze(0)
+    dz = (_rand(n_src if 'a' in gather else K, M, seed=71) * scale_a).to(DEV)
     x = (_rand(n_src if 'b' in gather else K, N, seed=72) * torch.logspace(-2, 2, N).unsqueeze(0)).to(DEV)
     a_idx = torch.randint(0, n_src, (K,), generator=g, dtype=torch.int32).to(DEV) if 'a' in gather else None
     b_idx = torch.randint(0, n_src, (K,), generator=g, dtype=torch.int32).to(DEV) if 'b' in gather else None
@@ -885,7 +886,7 @@ def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(N, K, gather, monkeypatc
     monkeypatch.setenv('SBR_TN_SPLIT', '1')
     assert torch.equal(ops.matmul_tn(dz, x, a_idx=a_idx, b_idx=b_idx, n_rows=K).double().cpu(), got['1'])
     d = ops.DeferredTN()
-    out = torch.empty(128, N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
     d.matmul_tn('t', dz, x, a_idx=a_idx, b_idx=b_idx, n_rows=K, out=out)
     d.finish()
     assert torch.equal(out.double().cpu(), got['1'])
