@@ -253,6 +253,19 @@ int sbr_bn_score_bwd_stats(const float* G, const float* U, const float* Z, float
 int sbr_bn_score_bwd_apply(const float* G, const float* U, const float* Z, float* dX, long B, int N, int D, const float* weight,
                            const float* save_mean, const float* save_rstd, const double* ws, float* dWeight, float* dBias,
                            double* ws_colsum, void* stream);
+/* sbr_bn_score_fwd + sbr_rec_loss_fwd_bwd (train/rec_losses.py:43-113, upstream gradient 1) + sbr_bn_score_bwd_stats in ONE
+ * launch (new: the fused training step): a user's N slot rows of Z stay in registers between the logits and the backward
+ * statistics, logits / dlogits make no round trip between kernels. logits may be NULL; dlogits [B, N]; dU [B, D]; loss_out [1];
+ * out3 (may be NULL) = (loss, loss, 0): the packed (total, rec, reg) scalars of a step without regularisation losses. ws: the
+ * BatchNorm's workspace as for sbr_bn_score_bwd_stats (totals in ws[0 .. 2 D) afterwards, ready for sbr_bn_score_bwd_apply);
+ * lws: sbr_bn_score_loss_workspace() bytes, zeroed ONCE by the caller and left zeroed by every call (calls that share it must not
+ * overlap). kind / labels / scale / shift as for sbr_rec_loss_fwd_bwd. N <= D / 4 and N <= 16 (sbr_bn_score_loss_supported). */
+int sbr_bn_score_loss_supported(int D, int N);
+long sbr_bn_score_loss_workspace(void);
+int sbr_bn_score_loss_fwd_bwd(const float* Z, const float* U, const float* save_mean, const float* save_rstd, const float* weight,
+                              const float* bias, int kind, const double* labels, double scale, float shift, float* logits,
+                              float* dlogits, float* dU, double* loss_out, double* out3, long B, int N, int D, double* ws, void* lws,
+                              long lws_bytes, void* stream);
 
 /* sbr_act_grad_gather that also accumulates the column sums of dZ (the bias gradient of its layer, modules/polylinear.py:51)
  * into a column-reduction workspace (17*C doubles, contract of sbr_colsum); sbr_colred_finish turns up to 8 pending

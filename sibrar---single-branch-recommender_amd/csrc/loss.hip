@@ -4,31 +4,12 @@
 // dtype notes that follow the reference: labels are float64 (data/dataloader.py:196), therefore BCE and BPR evaluate
 // BCEWithLogits in float64 and return a float64 scalar; sampled-softmax and InfoNCE stay in float32 (we accumulate their
 // sums in double and round once).
-#include "common.h"
-
-#define LOSS_BCE 0
-#define LOSS_BPR 1
-#define LOSS_SSM 2
+#include "loss_common.h"
 
 // loss scalars are zeroed by a one-thread kernel, not by hipMemsetAsync: inside a replayed hipGraph the 8-byte memset node was
 // observed to stop taking effect while another host thread issued copies (the scalar then kept a stale value for every later
 // replay); a kernel node has no such dependence on the runtime's fill path.
 __global__ void zero_f64_kernel(double* __restrict__ p) { p[0] = 0.0; }
-
-__device__ __forceinline__ double block_sum_d(double v, double* sm) {
-  v = sbr_wave_sum_d(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0)
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
-  return t;   // valid on thread 0
-}
-
-// softplus-form BCE-with-logits term: max(x,0) - x*y + log1p(exp(-|x|))
-__device__ __forceinline__ double bce_term(double x, double y) { return fmax(x, 0.0) - x * y + log1p(exp(-fabs(x))); }
-__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // one thread per batch row
 // MODE 3 = MODE 2 without a zeroed loss_out: every block leaves its partial sum in ws[1 + block], the block whose agent-scope
@@ -86,14 +67,23 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
     __shared__ double sm[4];
     const double t = block_sum_d(acc, sm);
     if (MODE == 3) {
+      __shared__ int last;
       if (threadIdx.x == 0) {
         __hip_atomic_store(&ws[1 + blockIdx.x], t * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the store has been performed (no L2 write-back: see fused_tail.hip)
         const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull);
-        if (before == gridDim.x - 1) {                           // every other block's partial is out
-          __threadfence();
-          double sum = 0.0;
-          for (unsigned i = 0; i < gridDim.x; ++i) sum += __hip_atomic_load(&ws[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == gridDim.x - 1;                          // every other block's partial is out
+      }
+      __syncthreads();
+      if (last) {
+        // all threads fetch the partial sums (one thread walking them pays a memory round trip per partial) and add them in a
+        // fixed pattern: thread i takes partials i, i + 256, ..., then the block sum
+        double part = 0.0;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
+          part += __hip_atomic_load(&ws[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                         // sm is reused
+        const double sum = block_sum_d(part, sm);
+        if (threadIdx.x == 0) {
           loss_out[0] = sum;
           if (out3) { out3[0] = sum; out3[1] = sum; out3[2] = 0.0; }
           __hip_atomic_store(reinterpret_cast<unsigned long long*>(ws), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -560,6 +560,7 @@ class FusedTrainStep:
         self._up_stream = None
         self._label_cache = {}
         self._loss_ws = None         # partial sums + arrival counter of the one-launch loss kernel (zeroed once, self-resetting)
+        self._tail_ws = None         # the same for the fused scorer + loss + statistics kernel
         self._packed = None
         # two-phase launch (and two graphs) when gradients are exchanged: see _reduce_user_part. SBR_FORCE_SPLIT=1 exercises
         # the same launch structure on one GPU.
@@ -619,13 +620,6 @@ class FusedTrainStep:
         ir = self.item.forward(i, pi, (seed, 1), si)                 # [B*N, D]; None: the trailing BatchNorm runs inside the scorer
         tail = self.item.tail if ir is None else None
         D = self.item.D
-        logits = a.f32(B, N)
-        if tail is not None:
-            z, mean, rstd = tail
-            bn = self.item.trailing
-            call('sbr_bn_score_fwd', ptr(z), ptr(ur), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), ptr(logits), B, N, D, st)
-        else:
-            call('sbr_score_dot_fwd', ptr(ur), ptr(ir), ptr(logits), B, N, D, st)
         rl = self.rec_loss
         if self.kind == 0:
             scale = 1.0 / (B * N) if rl.aggregator == 'mean' else 1.0
@@ -634,10 +628,40 @@ class FusedTrainStep:
         else:
             scale = 1.0 / B if rl.aggregator == 'mean' else 1.0
         shift = math.log(rl.n_items / rl.neg_train) if (self.kind == 2 and rl.train_neg_strategy == 'uniform') else 0.0
+        no_reg = self.user.reg_loss is None and self.item.reg_loss is None
+        self._packed = None
+        if (tail is not None and no_reg and B >= 1 and os.environ.get('SBR_FUSED_LOSS', '1') != '0'
+                and ops.lib().sbr_bn_score_loss_supported(int(D), int(N))):
+            # scorer forward, loss + dlogits and the first backward pass of the fused tail in ONE launch: the slot rows of a user
+            # stay in registers between the logits and the backward statistics (csrc/fused_tail.hip: bn_score_loss_kernel)
+            z, mean, rstd = tail
+            bn = self.item.trailing
+            need = int(ops.lib().sbr_bn_score_loss_workspace())
+            if self._tail_ws is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('the loss workspace must exist before a step is captured (run one plain step first)')
+                self._tail_ws = torch.zeros((need + 7) // 8, device=z.device, dtype=torch.float64)
+            loss = a.f64()
+            dlog = a.f32(B, N)
+            dU = a.f32(B, D)
+            self._packed = a.f64(3)
+            call('sbr_bn_score_loss_fwd_bwd', ptr(z), ptr(ur), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), self.kind, ptr(lab),
+                 scale, shift, None, ptr(dlog), ptr(dU), ptr(loss), ptr(self._packed), B, N, D, ptr(self.item._bn_ws(bn, D)),
+                 ptr(self._tail_ws), self._tail_ws.numel() * 8, st)
+            self.user.backward(dU, self.one32)
+            self._p2 = (None, loss, (dlog, ur))
+            return
+        logits = a.f32(B, N)
+        if tail is not None:
+            z, mean, rstd = tail
+            bn = self.item.trailing
+            call('sbr_bn_score_fwd', ptr(z), ptr(ur), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), ptr(logits), B, N, D, st)
+        else:
+            call('sbr_score_dot_fwd', ptr(ur), ptr(ir), ptr(logits), B, N, D, st)
         loss = a.f64()
         dlog = a.f32(B, N)
         self._packed = None
-        if self.user.reg_loss is None and self.item.reg_loss is None and B >= 1 and os.environ.get('SBR_LOSS_WS', '1') != '0':
+        if no_reg and B >= 1 and os.environ.get('SBR_LOSS_WS', '1') != '0':
             # one launch: no zeroing launch in front, block partial sums added in a fixed order, and the packed (total, rec, reg)
             # scalars of the step written by the same kernel (no regularisation losses: total = rec)
             need = int(ops.lib().sbr_rec_loss_workspace(B))

@@ -226,6 +226,58 @@ def test_rec_loss_one_launch_entry_point(kind, B, N):
     assert seen[0] == seen[1] == seen[2]
 
 
+@pytest.mark.parametrize('kind', [0, 1, 2])
+@pytest.mark.parametrize('B,N,D', [(1, 2, 64), (37, 11, 128), (8192, 11, 128), (3000, 16, 64), (5000, 5, 256), (70000, 3, 128)])
+def test_fused_scorer_loss_statistics_kernel(kind, B, N, D):
+    """sbr_bn_score_loss_fwd_bwd (scorer forward + recommendation loss + first backward pass of the fused tail in one launch)
+    against the sequence it replaces — sbr_bn_score_fwd, sbr_rec_loss_fwd_bwd, sbr_bn_score_bwd_stats (each pinned on its own
+    above / in the golden tests): logits, dlogits and dU bit for bit, the BatchNorm column sums and the loss to rounding, the packed
+    loss scalars, a second call on the same (self-resetting) workspaces with the same bits."""
+    from importlib import import_module
+    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    L = _lib.lib()
+    assert L.sbr_bn_score_loss_supported(D, N) == 1
+    z, u = (_rand(B * N, D, seed=61) * 2).to(DEV), _rand(B, D, seed=62).to(DEV)
+    mean, rstd = (_rand(D, seed=63) * 0.1).to(DEV), (_rand(D, seed=64).abs() + 0.5).to(DEV)
+    w, beta = (_rand(D, seed=65) * 0.5 + 1).to(DEV), (_rand(D, seed=66) * 0.1).to(DEV)
+    labels = torch.zeros(B, N, dtype=torch.float64)
+    labels[:, 0] = 1
+    labels = labels.to(DEV)
+    scale, shift, st = 1.0 / B, (0.37 if kind == 2 else 0.0), _lib.stream()
+    KD = 2 * D
+    # the three-kernel sequence
+    ws0 = torch.zeros(17 * KD, device=DEV, dtype=torch.float64)
+    lg0, dl0, du0 = torch.empty(B, N, device=DEV), torch.empty(B, N, device=DEV), torch.empty(B, D, device=DEV)
+    l0 = torch.zeros(1, device=DEV, dtype=torch.float64)
+    _lib.call('sbr_bn_score_fwd', z.data_ptr(), u.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), beta.data_ptr(),
+              lg0.data_ptr(), B, N, D, st)
+    _lib.call('sbr_rec_loss_fwd_bwd', kind, lg0.data_ptr(), labels.data_ptr(), B, N, scale, shift, l0.data_ptr(), dl0.data_ptr(), st)
+    _lib.call('sbr_bn_score_bwd_stats', dl0.data_ptr(), u.data_ptr(), z.data_ptr(), du0.data_ptr(), B, N, D, w.data_ptr(),
+              beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws0.data_ptr(), st)
+    # the fused kernel, twice on the same workspaces
+    ws1 = torch.zeros(17 * KD, device=DEV, dtype=torch.float64)
+    lws = torch.zeros(int(L.sbr_bn_score_loss_workspace()) // 8, device=DEV, dtype=torch.float64)
+    seen = []
+    for rep in range(2):
+        lg1, dl1, du1 = torch.full((B, N), 5.0, device=DEV), torch.empty(B, N, device=DEV), torch.empty(B, D, device=DEV)
+        l1, out3 = torch.full((1,), 9.0, device=DEV, dtype=torch.float64), torch.full((3,), 9.0, device=DEV, dtype=torch.float64)
+        _lib.call('sbr_bn_score_loss_fwd_bwd', z.data_ptr(), u.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(),
+                  beta.data_ptr(), kind, labels.data_ptr(), scale, shift, lg1.data_ptr() if rep == 0 else None, dl1.data_ptr(),
+                  du1.data_ptr(), l1.data_ptr(), out3.data_ptr(), B, N, D, ws1.data_ptr(), lws.data_ptr(), lws.numel() * 8, st)
+        if rep == 0:
+            assert torch.equal(lg1, lg0)
+        assert torch.equal(dl1, dl0)
+        assert torch.equal(du1, du0)
+        assert abs(l1.item() - l0.item()) <= 1e-12 * abs(l0.item()) + 1e-15
+        assert out3.cpu().tolist() == [l1.item(), l1.item(), 0.0]
+        tot0, tot1 = ws0[:KD].cpu(), ws1[:KD].cpu()
+        mag = tot0.abs().max().item() + 1e-30
+        assert bool(((tot1 - tot0).abs() <= 1e-9 * mag + 1e-12 * B).all())
+        assert bool((ws1[KD:] == 0).all()) and lws.view(torch.int64)[0].item() == 0      # replicas and counter left zeroed
+        seen.append((l1.item(), tot1.clone()))
+    assert seen[0][0] == seen[1][0]
+
+
 @pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8), (64, 40, 16), (1, 256, 64), (2, 300, 30),
                                    (1, 1000, 128)])
 def test_infonce_vs_oracle(G, N, D):
