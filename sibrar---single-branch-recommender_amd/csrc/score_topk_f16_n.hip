@@ -41,6 +41,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef S5_NS
 #define S5_NS 6                          // LDS ring slots of 16 KB (D = 128: 64-item tiles, D = 256: 32-item tiles)
 #endif
+#ifndef S5_EVABL
+#define S5_EVABL 0                        // lab (timing only, wrong results): 1 = the event window is never refilled
+#endif
 #define S5_EV_NONE 0xFFFFFFFFu            // padding event: its tile field matches no tile
 #define S5_CAPH 64                       // candidate entries per (user, lane half)
 
@@ -347,8 +350,9 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         w0 = w1; w1 = w2; w2 = w3;                                                                                       \
         if (--ev_rem == 0) {                                                                                             \
           w0 = n0; w1 = n1; w2 = n2; w3 = n3;                                                                            \
+          if constexpr (S5_EVABL == 1) { n0 = n1 = n2 = n3 = S5_EV_NONE; } else {                                       \
           const ev_quad qn = *(ev_quad_ptr)(evp + ev_q);                                                                 \
-          n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w;                                                                    \
+          n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w; }                                                                  \
           ev_rem = 4; ev_q += 4;                                                                                         \
         }                                                                                                                \
       }                                                                                                                  \

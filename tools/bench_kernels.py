@@ -66,7 +66,7 @@ def score_suite():
         uidx = torch.arange(Bu, device=dev)
         for excl in (False, True):
             fn = (lambda: ops.score_topk_f16(u, it, 20, uidx, indptr, indices)) if excl else (lambda: ops.score_topk_f16(u, it, 20))
-            ms = timeit(fn, reps=5, warm=1)
+            ms = timeit(fn, reps=15, warm=5)
             print(f'score_topk_f16 {Bu}x{I}x{D} excl={excl}: {ms:8.3f} ms  {2.0*Bu*I*D/ms/1e9:8.1f} TFLOP/s')
 
 
