@@ -16,7 +16,9 @@
 // B = 8192 and for longer than the GPU work at B = 256; with this producer the launch thread is the only Python on the path.
 // Generator states are handed in when an epoch starts and handed back when it ends (or is stopped), so numpy's global stream
 // and the entities' generators continue exactly where the reference's would.
+#include <chrono>
 #include <condition_variable>
+#include <stdio.h>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -37,6 +39,8 @@ struct Mt {
   uint32_t key[MT_N];
   int p;
   uint32_t rng, mask;
+  uint32_t out[MT_N];                                        // tempered outputs of key[tp0 .. MT_N): see fill()
+  int tp = MT_N;                                             // key position out[] was tempered for up to MT_N (MT_N: none)
   void regen() {
     uint32_t* mt = key;
     int i;
@@ -68,6 +72,33 @@ struct Mt {
       y ^= (y >> 18);
       const uint32_t v = y & mask;
       if (v <= rng) return (long)v;
+    }
+  }
+  // n draws of randint(0, rng + 1) into dst (through map when given): the same words in the same order as n calls of next(), but
+  // the tempering runs over the whole remaining state block at once (a loop the compiler vectorises) and the rejection loop only
+  // masks and compares — the per-call form spent 0.4 ms on the 81,920 negatives of a batch of 8,192
+  void fill(long n, long* dst, const long* map) {
+    if (rng == 0) { for (long i = 0; i < n; ++i) dst[i] = map ? map[0] : 0; return; }
+    long i = 0;
+    while (i < n) {
+      if (p == MT_N) { regen(); p = 0; }
+      const int lo = p;
+      for (int q = lo; q < MT_N; ++q) {
+        uint32_t y = key[q];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        out[q] = y & mask;
+      }
+      int q = lo;
+      const uint32_t r = rng;
+      for (; q < MT_N && i < n; ++q) {
+        const uint32_t v = out[q];
+        dst[i] = map ? map[v <= r ? v : 0] : (long)v;        // (a rejected word is overwritten by the next accepted one)
+        i += v <= r;
+      }
+      p = q;
     }
   }
 };
@@ -209,7 +240,13 @@ struct Producer {
   bool running = false, stop = false, done = false;
   long produced = 0;
   std::string error;
+  // stage clocks of the producer thread (seconds, summed over the epoch; printed at sbr_producer_stop when SBR_PRODUCER_TIMING=1)
+  double t_wait = 0, t_draw = 0, t_member = 0, t_pack = 0, t_mod = 0, t_upload = 0;
 };
+
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static bool hip_ok(Producer* p, hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -244,9 +281,11 @@ static bool membership(Producer* p, long n) {
 
 static bool produce_one(Producer* p, long bno, std::vector<long>& desc) {
   const int slot = (int)(bno % p->n_slots);
+  double t0 = now_s();
   if (p->used[slot]) {
     if (!hip_ok(p, hipEventSynchronize(p->consumed[slot]), "producer: wait for the consumer")) return false;
   }
+  { const double t1 = now_s(); p->t_wait += t1 - t0; t0 = t1; }
   const long lo = bno * p->stride + p->first;
   long B = p->B;
   if (lo + B > p->n_inter) B = p->n_inter - lo;
@@ -259,12 +298,13 @@ static bool produce_one(Producer* p, long bno, std::vector<long>& desc) {
   long* values = p->values.data();
   long* todo = p->todo.data();
   const bool ident = p->items_in_split.empty();
-  for (long s = 0; s < total; ++s) {
-    const long r = p->mt.next();
-    values[s] = ident ? r : p->items_in_split[r];
-  }
+  p->mt.fill(total, values, ident ? nullptr : p->items_in_split.data());
   long m = total;
-  for (long s = 0; s < total; ++s) { p->q_users[s] = users[s % B]; p->q_items[s] = values[s]; todo[s] = s; }
+  for (int j = 0; j < p->n_neg; ++j) {                       // slot s = j * B + b belongs to user b (no division per slot)
+    const long base = (long)j * B;
+    for (long b = 0; b < B; ++b) { p->q_users[base + b] = users[b]; p->q_items[base + b] = values[base + b]; todo[base + b] = base + b; }
+  }
+  { const double t1 = now_s(); p->t_draw += t1 - t0; t0 = t1; }
   bool first_round = true;
   while (m > 0) {
     if (!first_round) {
@@ -283,6 +323,7 @@ static bool produce_one(Producer* p, long bno, std::vector<long>& desc) {
       if (p->q_flags[q]) todo[m2++] = todo[q];
     m = m2;
   }
+  { const double t1 = now_s(); p->t_member += t1 - t0; t0 = t1; }
   // ---- packed staging buffer: [u | u[0] | items | items[0] | user draw | item draw | seed], 16-byte aligned segments
   unsigned char* h = p->slot_host[slot];
   long off[6];
@@ -305,6 +346,7 @@ static bool produce_one(Producer* p, long bno, std::vector<long>& desc) {
     for (long b = 0; b < B; ++b) hi_[b * N + 1 + j] = v[b];
   }
   hi_[B * N] = hi_[0];
+  { const double t1 = now_s(); p->t_pack += t1 - t0; t0 = t1; }
   desc.assign(DESC_WORDS, 0);
   long* cu = desc.data() + 11;
   long* ci = desc.data() + 19;
@@ -315,11 +357,13 @@ static bool produce_one(Producer* p, long bno, std::vector<long>& desc) {
   }
   draw_modalities(p->ent[1], B * N, (int8_t*)(h + off[3]), ci);
   if (p->pad) pad_counts(ci, p->ent[1].n_mod, Ri);
+  { const double t1 = now_s(); p->t_mod += t1 - t0; t0 = t1; }
   p->n_prepared += 1;
   *(long*)(h + off[4]) = (p->seed_base + 2 * p->n_prepared) & 0x3FFFFFFFFFFFFFFFL;
   if (!hip_ok(p, hipMemcpyAsync(p->slot_dev[slot], h, off[5], hipMemcpyHostToDevice, p->stream), "producer: upload")) return false;
   if (!hip_ok(p, hipEventRecord(p->ready[slot], p->stream), "producer: event")) return false;
   p->used[slot] = 1;
+  p->t_upload += now_s() - t0;
   desc[0] = slot; desc[1] = B; desc[2] = off[5];
   for (int q = 0; q < 6; ++q) desc[3 + q] = off[q];
   desc[9] = Ru; desc[10] = Ri; desc[27] = bno;
@@ -438,6 +482,7 @@ int sbr_producer_start(void* handle, const long* rows_e, const long* cols_e, lon
   p->queue.clear();
   p->stop = false; p->done = false; p->produced = 0; p->error.clear();
   for (auto& u : p->used) u = 0;
+  p->t_wait = p->t_draw = p->t_member = p->t_pack = p->t_mod = p->t_upload = 0;
   p->running = true;
   p->th = std::thread(run, p);
   return SBR_OK;
@@ -499,6 +544,12 @@ int sbr_producer_stop(void* handle, unsigned int* mt_key, int* mt_pos, unsigned 
     }
     p->th.join();
     p->running = false;
+    if (getenv("SBR_PRODUCER_TIMING") && atoi(getenv("SBR_PRODUCER_TIMING")) == 1 && p->produced > 0) {
+      const double n = (double)p->produced, ms = 1e3 / n;
+      fprintf(stderr, "[sbr producer] %ld batches: wait for a free slot %.3f | draws %.3f | membership rounds %.3f | pack %.3f | modality "
+                      "draws %.3f | upload %.3f ms per batch\n", p->produced, p->t_wait * ms, p->t_draw * ms, p->t_member * ms,
+              p->t_pack * ms, p->t_mod * ms, p->t_upload * ms);
+    }
   }
   if (mt_key) memcpy(mt_key, p->mt.key, sizeof(p->mt.key));
   if (mt_pos) *mt_pos = p->mt.p;
