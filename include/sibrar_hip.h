@@ -70,6 +70,11 @@ int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx, const floa
                           void* workspace, long workspace_bytes, int* splits_out, void* stream);
 int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms, const int* Ns,
                             const int* splits, void* stream);
+/* the same launch also finishes up to 8 pending column reductions (sbr_colred_finish: out[i] = sum of the replicas of entry i of
+ * its workspace, replicas left zeroed): the two finishing launches at the end of a backward pass become one. */
+int sbr_splitk_reduce_multi_fin(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
+                                const int* Ns, const int* splits, int fin_count, const void* const* fin_workspaces,
+                                const void* const* fin_outs, const int* fin_widths, void* stream);
 
 /* Weights-resident variant for the shared MLP's own products (N = K = 128, no gathers): every wave keeps its half of the 128 x 128
  * weight in registers, only A streams through LDS (csrc/gemm_wres_f32.hip); bit-identical to sbr_gemm_f32 on the same operands.

@@ -549,8 +549,22 @@ __global__ void splitk_reduce_multi_kernel(SplitkMulti a) {
 // The same with 16 bytes per lane (every N[q] a multiple of 4, slabs 16-byte aligned): a block sums 128 consecutive elements, four
 // slab loads in flight per lane. Per element the summation order is the scalar kernel's (z = zg, zg + 8, ... per group, then the
 // eight groups in order), so the results are bit-identical to it; 26 -> ~15 us for the step's three dW products (84 MB of slabs).
-__global__ __launch_bounds__(256) void splitk_reduce_multi4_kernel(SplitkMulti a) {
+// Column-reduction workspaces finished by the same launch (sbr_splitk_reduce_multi_fin): slices n_red .. n_red + count - 1 of grid.y
+struct SplitkFin {
+  double* ws[8];
+  float* out[8];
+  int C[8];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_multi4_kernel(SplitkMulti a, SplitkFin f, int n_red) {
   __shared__ float4 part[8][32];
+  if ((int)blockIdx.y >= n_red) {                            // a pending column sum -> its float vector (replicas left zeroed)
+    const int fq = blockIdx.y - n_red;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < f.C[fq]) f.out[fq][i] = (float)sbr_colred_take(f.ws[fq], f.C[fq], i);
+    return;
+  }
   const int q = blockIdx.y;
   const int e_local = threadIdx.x & 31, zg = threadIdx.x >> 5;
   const long total = (long)a.M[q] * a.N[q];
@@ -588,10 +602,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi4_kernel(SplitkMulti a
   }
 }
 
+static int splitk_reduce_multi_impl(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
+                                    const int* Ns, const int* splits, const SplitkFin& fin, void* stream);
+
 // slabs / outs: HOST arrays of device pointers; ldcs, Ms, Ns, splits: HOST arrays (copied into the launch)
 extern "C" int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
                                        const int* Ns, const int* splits, void* stream) {
-  if (count == 0) return SBR_OK;
+  SplitkFin fin;
+  fin.count = 0;
+  return splitk_reduce_multi_impl(count, slabs, outs, ldcs, Ms, Ns, splits, fin, stream);
+}
+
+// The same launch also finishes up to 8 pending column reductions (what sbr_colred_finish does: out[i] = sum of the workspace's
+// replicas of entry i, replicas left zeroed) — the two finishing launches at the end of a backward pass become one.
+extern "C" int sbr_splitk_reduce_multi_fin(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
+                                           const int* Ns, const int* splits, int fin_count, const void* const* fin_workspaces,
+                                           const void* const* fin_outs, const int* fin_widths, void* stream) {
+  SBR_REQUIRE(fin_count >= 0 && fin_count <= 8 && (fin_count == 0 || (fin_workspaces && fin_outs && fin_widths)),
+              "sbr_splitk_reduce_multi_fin: 0..8 column reductions per call");
+  SplitkFin fin;
+  fin.count = fin_count;
+  for (int q = 0; q < fin_count; ++q) {
+    SBR_REQUIRE(fin_workspaces[q] && fin_outs[q] && fin_widths[q] >= 1, "sbr_splitk_reduce_multi_fin: null entry %d", q);
+    fin.ws[q] = (double*)fin_workspaces[q]; fin.out[q] = (float*)fin_outs[q]; fin.C[q] = fin_widths[q];
+  }
+  return splitk_reduce_multi_impl(count, slabs, outs, ldcs, Ms, Ns, splits, fin, stream);
+}
+
+__global__ void splitk_fin_only_kernel(SplitkFin f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < f.C[blockIdx.y]) f.out[blockIdx.y][i] = (float)sbr_colred_take(f.ws[blockIdx.y], f.C[blockIdx.y], i);
+}
+
+static int splitk_reduce_multi_impl(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms,
+                                    const int* Ns, const int* splits, const SplitkFin& fin, void* stream) {
+  int cmax = 0;
+  for (int q = 0; q < fin.count; ++q) cmax = fin.C[q] > cmax ? fin.C[q] : cmax;
+  if (count == 0) {
+    if (fin.count > 0) {
+      splitk_fin_only_kernel<<<dim3(sbr_cdiv(cmax, 256), fin.count), 256, 0, (hipStream_t)stream>>>(fin);
+      SBR_CHECK_LAUNCH("sbr_splitk_reduce_multi_fin");
+    }
+    return SBR_OK;
+  }
   SBR_REQUIRE(count >= 1 && count <= 8 && slabs && outs && ldcs && Ms && Ns && splits, "sbr_splitk_reduce_multi: 1..8 products per call");
   SplitkMulti a;
   long most = 0;
@@ -603,8 +656,15 @@ extern "C" int sbr_splitk_reduce_multi(int count, const void* const* slabs, cons
   }
   bool vec4 = true;
   for (int q = 0; q < count; ++q) vec4 = vec4 && (Ns[q] % 4 == 0) && ((((uintptr_t)slabs[q]) & 15) == 0);
-  if (vec4) splitk_reduce_multi4_kernel<<<dim3(sbr_cdiv(most, 128), count), 256, 0, (hipStream_t)stream>>>(a);
-  else splitk_reduce_multi_kernel<<<dim3(sbr_cdiv(most, 32), count), 256, 0, (hipStream_t)stream>>>(a);
+  if (vec4) {
+    int gx = sbr_cdiv(most, 128);
+    const int gfin = sbr_cdiv(cmax, 256);
+    if (gfin > gx) gx = gfin;
+    splitk_reduce_multi4_kernel<<<dim3(gx, count + fin.count), 256, 0, (hipStream_t)stream>>>(a, fin, count);
+  } else {
+    splitk_reduce_multi_kernel<<<dim3(sbr_cdiv(most, 32), count), 256, 0, (hipStream_t)stream>>>(a);
+    if (fin.count > 0) splitk_fin_only_kernel<<<dim3(sbr_cdiv(cmax, 256), fin.count), 256, 0, (hipStream_t)stream>>>(fin);
+  }
   SBR_CHECK_LAUNCH("sbr_splitk_reduce_multi");
   return SBR_OK;
 }

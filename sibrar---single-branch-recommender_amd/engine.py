@@ -413,9 +413,10 @@ class _EntityRun:
             ps = fe.front_params()
             fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps],
                               pending=pending, tn=self.tn)
+        took = False
         if self.tn is not None:
-            self.tn.finish()
-        if pending:
+            took = self.tn.finish(pending)             # ... and the pending bias-gradient column sums, in the same launch
+        if pending and not took:
             ops.colred_finish(pending)
         if br is not None:
             br.join()

@@ -248,18 +248,33 @@ class DeferredTN:
         self.pending.append((ws, out, M, N, splits.value))
         return out
 
-    def finish(self):
+    def finish(self, colred=None):
+        """Sums the slabs of the pending products. ``colred`` (optional): [(workspace, out float vector [C])] of folded column sums
+        — at most 8, with at most 8 pending products — finished by the same launch (``sbr_splitk_reduce_multi_fin``) instead of a
+        ``colred_finish`` launch of their own; returns True when they were taken."""
         import ctypes
+        took = False
+        fuse = colred and 0 < len(colred) <= 8 and 0 < len(self.pending) <= 8
         for lo in range(0, len(self.pending), 8):
             part = self.pending[lo:lo + 8]
             n = len(part)
-            arr = lambda ct, vals: ctypes.cast((ct * n)(*vals), ctypes.c_void_p)
+            arr = lambda ct, vals, m=n: ctypes.cast((ct * m)(*vals), ctypes.c_void_p)
+            args = (n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]),
+                    arr(ctypes.c_void_p, [p[1].data_ptr() for p in part]), arr(ctypes.c_long, [p[1].stride(0) for p in part]),
+                    arr(ctypes.c_int, [p[2] for p in part]), arr(ctypes.c_int, [p[3] for p in part]),
+                    arr(ctypes.c_int, [p[4] for p in part]))
             # timed as one launch; the key carries every product's (M, N, slabs) so that a reader can apportion it by slab bytes
-            _timed(('splitk_reduce_multi', tuple((p[2], p[3], p[4]) for p in part)), lambda: call('sbr_splitk_reduce_multi', n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]),
-                 arr(ctypes.c_void_p, [p[1].data_ptr() for p in part]), arr(ctypes.c_long, [p[1].stride(0) for p in part]),
-                 arr(ctypes.c_int, [p[2] for p in part]), arr(ctypes.c_int, [p[3] for p in part]),
-                 arr(ctypes.c_int, [p[4] for p in part]), stream()))
+            key = ('splitk_reduce_multi', tuple((p[2], p[3], p[4]) for p in part))
+            if fuse:
+                m = len(colred)
+                fin = (m, arr(ctypes.c_void_p, [w.data_ptr() for w, _ in colred], m), arr(ctypes.c_void_p, [o.data_ptr() for _, o in colred], m),
+                       arr(ctypes.c_int, [o.numel() for _, o in colred], m))
+                _timed(key, lambda: call('sbr_splitk_reduce_multi_fin', *args, *fin, stream()))
+                took = True
+            else:
+                _timed(key, lambda: call('sbr_splitk_reduce_multi', *args, stream()))
         self.pending = []
+        return took
 
 
 _COLSUM_WS = {}

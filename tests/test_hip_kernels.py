@@ -945,6 +945,40 @@ def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(M, N, K, gather, monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n_fin', [1, 3, 8])
+def test_slab_reducer_also_finishes_pending_column_sums(n_fin):
+    """DeferredTN.finish(colred) = sbr_splitk_reduce_multi_fin: one launch sums the split-K slabs of the pending dW products AND turns
+    pending column-reduction workspaces into their float vectors — the same bits as the two launches (finish() + colred_finish), the
+    replicas left zeroed; widths larger than the largest product's slice count included."""
+    ops = S().ops
+    dz, x = _rand(9000, 128, seed=81).to(DEV), _rand(9000, 256, seed=82).to(DEV)
+    widths = [128, 512, 64, 1024, 128, 256, 128, 4][:n_fin]
+    dys = [_rand(5000, C, seed=90 + i).to(DEV) for i, C in enumerate(widths)]
+    ys = [_rand(5000, C, seed=70 + i).to(DEV) for i, C in enumerate(widths)]
+    res = {}
+    for fused in (False, True):
+        pend = []
+        for dy, y in zip(dys, ys):
+            ws = ops.new_colsum_ws(DEV, dy.shape[1])
+            ops.act_grad_colsum(dy, y, 1, ws)
+            pend.append((ws, torch.full((dy.shape[1],), 7.0, device=DEV)))
+        d = ops.DeferredTN()
+        out = torch.empty(128, 256, device=DEV)
+        d.matmul_tn('t', dz, x, out=out)
+        if fused:
+            assert d.finish(pend) is True
+        else:
+            assert not d.finish()
+            ops.colred_finish(pend)
+        res[fused] = (out.clone(), [o.clone() for _, o in pend])
+        for ws, o in pend:
+            assert bool((ws[o.numel():] == 0).all())            # replicas left zeroed
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('D', [128, 256])
 def test_fused_f16_scorer_long_tailed_exclusion_rows(D):
     """The exclusion event stream of the narrow-wave kernel (csrc/score_topk_f16_n.hip) on rows of very different lengths: users

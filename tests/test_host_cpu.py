@@ -214,13 +214,21 @@ def test_two_rank_gloo_data_parallel_and_item_sharding(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(root=ROOT))
     import socket
-    with socket.socket() as sock:                     # a free port (a fixed one collides with lingering sockets of earlier runs)
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for attempt in range(3):
+        with socket.socket() as sock:                 # a free port (a fixed one collides with lingering sockets of earlier runs)
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        # the port is free when it is picked and may be taken by the time the store binds it, and the gloo rendezvous itself can time
+        # out on a loaded host: retry the RENDEZVOUS (never an assertion of the worker, whose output carries 'AssertionError')
+        infra = any(p.returncode != 0 and 'AssertionError' not in o and
+                    any(k in o for k in ('Address already in use', 'EADDRINUSE', 'Connection', 'connect', 'timed out', 'Timeout', 'store'))
+                    for p, o in zip(procs, outs))
+        if not infra:
+            break
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f'rank {r} failed:\n{o}'
         assert f'rank {r} ok' in o
