@@ -104,12 +104,15 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     # W warm-up steps (graph capture, allocator), then SETTLE more untimed steps: the loader's two pipeline stages run up to
     # 2 * prefetch + 2 batches ahead while the first steps compile / capture, and a timed region that starts on that head start
     # would report the consumer's burst rate instead of the sustained rate of the whole pipeline.
-    run_steps(S, trainer, it, warmup + SETTLE, world)
+    run_steps(S, trainer, it, warmup, world)
     # no cyclic-garbage collection inside the timed region (a generation-2 pass over the loader's queues and tensors is a
-    # multi-millisecond pause on the launch thread); collected before, re-enabled after
+    # multi-millisecond pause on the launch thread); collected before, re-enabled after. The collection runs BEFORE the settle steps:
+    # a pause of tens of milliseconds right in front of the timed region leaves the GPU idle long enough for its clocks to drop, and
+    # the first ~10 ms of the timed steps then run slower (0.61 instead of 0.57 ms per step over 20 steps, tools/lab/host_timeline.py).
     import gc
     gc.collect()
     gc.disable()
+    run_steps(S, trainer, it, SETTLE, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
