@@ -330,6 +330,10 @@ int sbr_infonce_gemm_bwd(const float* A, const float* B, long ld, long G, int N,
  * kind 0 = torch.optim.AdamW, 1 = torch.optim.Adam; step is the 1-based step count. */
 int sbr_adam_step(int kind, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                   double wd, long step, void* stream);
+/* optimizer.step(); optimizer.zero_grad() (train/trainer.py:221-222) in one launch: every gradient element is reset to +0 once it
+ * has been consumed; elements that are +0 already are not written. */
+int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                            double wd, long step, void* stream);
 /* The same dense-optimizer semantics for a [n_rows, D] lookup table, deferred row by row (train/trainer.py:62-68 updates every row
  * every step; a row without gradient can take its zero-gradient updates later, in order, bit-identically). mode 0: bring the rows
  * named by ids (int64 or int32, optionally through rowmap) up to step - 1 (before the forward pass reads them); mode 1: the same,

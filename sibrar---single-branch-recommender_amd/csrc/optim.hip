@@ -30,14 +30,20 @@ __device__ __forceinline__ void adam_element(float& pe, float ge, float& me, flo
   pe = pe - step_size * (me / denom);
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// ZERO: the gradient element is reset to +0 once it has been consumed (optimizer.zero_grad() of train/trainer.py:222 folded into the
+// step). Only elements that are not +0 already are written, so the mostly-zero gradients of the embedding tables (8 % of the user
+// table's rows see a gradient in a step of the bench) cost next to nothing: the separate fill wrote all 77 MB of the c2 gradient.
+template <bool ZERO>
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, AdamHyper h, float step_size, float bc2_sqrt) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float pe = p[e], me = m[e], ve = v[e];
-    adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
+    const float ge = g[e];
+    adam_element(pe, ge, me, ve, h, step_size, bc2_sqrt);
     p[e] = pe;
     m[e] = me;
     v[e] = ve;
+    if (ZERO && __float_as_uint(ge) != 0u) g[e] = 0.f;
   }
 }
 
@@ -146,8 +152,23 @@ extern "C" int sbr_adam_step(int kind, float* p, const float* g, float* m, float
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
-  adamw_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
+  adamw_kernel<false><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, const_cast<float*>(g), m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
   SBR_CHECK_LAUNCH("sbr_adam_step");
+  return SBR_OK;
+}
+
+// sbr_adam_step followed by zeroing the gradient (optimizer.step(); optimizer.zero_grad(), train/trainer.py:221-222) in one launch
+extern "C" int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                                       double eps, double wd, long step, void* stream) {
+  SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_step_zero_grad: unknown kind %d", kind);
+  SBR_REQUIRE(p && g && m && v, "sbr_adam_step_zero_grad: null operand");
+  SBR_REQUIRE(step >= 1, "sbr_adam_step_zero_grad: step must be >= 1");
+  if (n == 0) return SBR_OK;
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
+  adamw_kernel<true><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
+  SBR_CHECK_LAUNCH("sbr_adam_step_zero_grad");
   return SBR_OK;
 }
 

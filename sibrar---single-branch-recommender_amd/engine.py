@@ -891,8 +891,7 @@ class FusedTrainStep:
             # ---- reduce + update
             self._reduce_rest(pending)
             if self.deferred is None:
-                self.opt.step_flat()
-                self.opt.fp.grad.zero_()
+                self.opt.step_flat(zero_grad=True)                   # step() + zero_grad() in the optimizer's own launch
             else:
                 d, g = self.deferred, self.opt.fp.grad
                 self.opt.step_flat(skip=(d.lo, d.hi))

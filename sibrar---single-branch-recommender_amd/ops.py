@@ -721,8 +721,10 @@ def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, exc
 
 
 # ---- optimizer steps ----------------------------------------------------------------------------------------------------------
-def adam_step(kind: int, p, g, m, v, lr, b1, b2, eps, wd, step: int):
-    call('sbr_adam_step', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, wd, step, stream())
+def adam_step(kind: int, p, g, m, v, lr, b1, b2, eps, wd, step: int, zero_grad: bool = False):
+    """One dense Adam / AdamW step; ``zero_grad``: the gradient is reset by the same launch (step() + zero_grad())."""
+    call('sbr_adam_step_zero_grad' if zero_grad else 'sbr_adam_step', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps,
+         wd, step, stream())
 
 
 def adagrad_step(p, g, s, lr, eps, wd):

@@ -91,8 +91,9 @@ class FusedOptimizer:
         self._sync_grads()
         self.step_flat()
 
-    def step_flat(self, skip=None):
-        """Update from the flat gradient buffer as it is (the fused step writes gradients there directly).
+    def step_flat(self, skip=None, zero_grad: bool = False):
+        """Update from the flat gradient buffer as it is (the fused step writes gradients there directly). ``zero_grad``: the
+        gradient buffer is reset by the optimizer's own launch (Adam / AdamW; Adagrad zeroes it with a fill).
         ``skip`` = (lo, hi): leave that range of the flat buffers alone — a lookup table whose rows the fused step updates
         itself, deferred row by row (engine.DeferredTable). A step without ``skip`` first brings such a table up to date."""
         if skip is None and self.deferred is not None:
@@ -101,12 +102,14 @@ class FusedOptimizer:
         fp = self.fp
         if self.name == 'adagrad':
             ops.adagrad_step(fp.flat, fp.grad, self.m, self.lr, 1e-10, self.wd)
+            if zero_grad:
+                fp.grad.zero_()
             return
         kind = 0 if self.name == 'adamw' else 1
         for lo, hi in ([(0, fp.total)] if skip is None else [(0, skip[0]), (skip[1], fp.total)]):
             if hi > lo:
                 ops.adam_step(kind, fp.flat[lo:hi], fp.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, 0.9, 0.999, 1e-8,
-                              self.wd, self.step_count)
+                              self.wd, self.step_count, zero_grad=zero_grad)
         if skip is None and self.deferred is not None:
             self.deferred.mark_all_current()           # this step updated the table densely
 

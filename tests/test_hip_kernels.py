@@ -295,6 +295,30 @@ def test_infonce_vs_oracle(G, N, D):
     close(bd.grad.cpu(), br.grad, rtol=2e-4, atol=1e-6, what='db', norm_rtol=1e-4)
 
 
+@pytest.mark.parametrize('kind', [0, 1])
+def test_adam_step_with_folded_zero_grad(kind):
+    """sbr_adam_step_zero_grad = sbr_adam_step + gradient.zero_() in one launch: the same parameter / moment bits, and a gradient
+    buffer of +0.0 afterwards whatever it held (zeros, negative zeros, a NaN)."""
+    ops = S().ops
+    n = 100003
+    g0 = _rand(n, seed=5)
+    g0[::3] = 0.0
+    g0[1::7] = -0.0
+    g0[5] = float('nan')
+    res = {}
+    for fold in (False, True):
+        p, m, v = _rand(n, seed=1).to(DEV), (_rand(n, seed=2) * 0.1).to(DEV), (_rand(n, seed=3).abs() * 0.01).to(DEV)
+        g = g0.clone().to(DEV)
+        for step in (1, 2):
+            ops.adam_step(kind, p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, zero_grad=fold)
+            if fold:
+                assert bool((g.view(torch.int32) == 0).all())
+            g.copy_(g0)
+        res[fold] = (p.cpu(), m.cpu(), v.cpu())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 @pytest.mark.parametrize('name', ['adamw', 'adam', 'adagrad'])
 def test_fused_optimizer_vs_update_rules(name):
     ops = S().ops

@@ -184,7 +184,11 @@ def test_fused_step_against_g4_directly(case):
     opt = S().FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=0.)
     fused = S().FusedTrainStep(net, _loss(case['loss']), opt, use_graph=True)
     seen = []
-    opt.step_flat = lambda *a, **k: seen.append({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
+    def _record(*a, **k):                                      # stands in for the optimizer launch (which also resets the gradient)
+        seen.append({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
+        if k.get('zero_grad'):
+            opt.fp.grad.zero_()
+    opt.step_flat = _record
     u, i, labels = (torch.from_numpy(z[f'{n}/{k}']) for k in ('u', 'i', 'labels'))
     golden = sub(z, f'{n}/g/')
     sc = gscale(golden.values())
@@ -382,7 +386,11 @@ def test_c3_step_at_full_shapes_against_the_cpu_oracle():
     lossf = S().RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=10)
     fused = S().FusedTrainStep(net, lossf, opt)
     seen = []
-    opt.step_flat = lambda *a, **k: seen.append({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
+    def _record(*a, **k):                                      # stands in for the optimizer launch (which also resets the gradient)
+        seen.append({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
+        if k.get('zero_grad'):
+            opt.fp.grad.zero_()
+    opt.step_flat = _record
     loader = S().NegativeSamplingDataLoader(ds, batch_size=256, shuffle=True)
     u, i, labels = next(iter(loader))
     draws = fused.draw(u.shape, i.shape)
@@ -435,7 +443,11 @@ def test_c4_step_on_one_gpu_at_full_table_shapes():
     fused = S().FusedTrainStep(nets[1], lossf, opts[1])
     real_step = opts[1].step_flat
     seen = []
-    opts[1].step_flat = lambda *a, **k: seen.append(opts[1].fp.grad.clone())
+    def _record(*a, **k):                                      # stands in for the optimizer launch (which also resets the gradient)
+        seen.append(opts[1].fp.grad.clone())
+        if k.get('zero_grad'):
+            opts[1].fp.grad.zero_()
+    opts[1].step_flat = _record
     rng = np.random.default_rng(8)
     u = torch.from_numpy(rng.integers(0, ds.n_users, size=256))
     i = torch.from_numpy(rng.integers(0, ds.n_items, size=(256, 11)))
