@@ -333,7 +333,9 @@ int sbr_adam_step(int kind, float* p, const float* g, float* m, float* v, long n
 /* optimizer.step(); optimizer.zero_grad() (train/trainer.py:221-222) in one launch: every gradient element is reset to +0 once it
  * has been consumed; elements that are +0 already are not written. */
 int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
-                            double wd, long step, void* stream);
+                            double wd, long step, const double* copy_src, double* copy_dst, int copy_n, void* stream);
+/* copy_n (0 .. 256) doubles copy_src -> copy_dst ride on the same launch: the loss scalars of a captured step, whose buffer the
+ * next replay overwrites (copy_n = 0: no copy). */
 /* The same dense-optimizer semantics for a [n_rows, D] lookup table, deferred row by row (train/trainer.py:62-68 updates every row
  * every step; a row without gradient can take its zero-gradient updates later, in order, bit-identically). mode 0: bring the rows
  * named by ids (int64 or int32, optionally through rowmap) up to step - 1 (before the forward pass reads them); mode 1: the same,

@@ -33,9 +33,13 @@ __device__ __forceinline__ void adam_element(float& pe, float ge, float& me, flo
 // ZERO: the gradient element is reset to +0 once it has been consumed (optimizer.zero_grad() of train/trainer.py:222 folded into the
 // step). Only elements that are not +0 already are written, so the mostly-zero gradients of the embedding tables (8 % of the user
 // table's rows see a gradient in a step of the bench) cost next to nothing: the separate fill wrote all 77 MB of the c2 gradient.
+// cp_n > 0: the launch also copies cp_n doubles cp_src -> cp_dst (the loss scalars of the step, which live in a buffer the next
+// replay of the captured step overwrites: one 4.9 us copy launch per step less).
 template <bool ZERO>
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             long n, AdamHyper h, float step_size, float bc2_sqrt) {
+                             long n, AdamHyper h, float step_size, float bc2_sqrt, const double* __restrict__ cp_src = nullptr,
+                             double* __restrict__ cp_dst = nullptr, int cp_n = 0) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < cp_n) cp_dst[threadIdx.x] = cp_src[threadIdx.x];
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float pe = p[e], me = m[e], ve = v[e];
     const float ge = g[e];
@@ -159,15 +163,19 @@ extern "C" int sbr_adam_step(int kind, float* p, const float* g, float* m, float
 
 // sbr_adam_step followed by zeroing the gradient (optimizer.step(); optimizer.zero_grad(), train/trainer.py:221-222) in one launch
 extern "C" int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
-                                       double eps, double wd, long step, void* stream) {
+                                       double eps, double wd, long step, const double* copy_src, double* copy_dst, int copy_n,
+                                       void* stream) {
   SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_step_zero_grad: unknown kind %d", kind);
   SBR_REQUIRE(p && g && m && v, "sbr_adam_step_zero_grad: null operand");
   SBR_REQUIRE(step >= 1, "sbr_adam_step_zero_grad: step must be >= 1");
+  SBR_REQUIRE(copy_n >= 0 && copy_n <= 256 && (copy_n == 0 || (copy_src && copy_dst)), "sbr_adam_step_zero_grad: bad copy request");
+  SBR_REQUIRE(n >= 1 || copy_n == 0, "sbr_adam_step_zero_grad: a copy needs a non-empty step");
   if (n == 0) return SBR_OK;
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
-  adamw_kernel<true><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2));
+  adamw_kernel<true><<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, h, (float)(lr / bc1), (float)sqrt(bc2), copy_src, copy_dst,
+                                                                   copy_n);
   SBR_CHECK_LAUNCH("sbr_adam_step_zero_grad");
   return SBR_OK;
 }

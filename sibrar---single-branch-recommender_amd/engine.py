@@ -883,7 +883,7 @@ class FusedTrainStep:
                     if cs.graph2 is not None:
                         cs.graph2.replay()
                     self.n_replays += 1
-                    out = cs.out.clone().unbind(0)
+                    out = cs.out                                     # the graph's static buffer: copied out below
             if out is None:
                 self._phase1(pb.u[:-1].view(pb.u_shape), pb.i[:-1].view(pb.i_shape), pb.lab, pb.pu, pb.pi, pb.su, pb.si, pb.seed)
                 pending = self._reduce_user_part()
@@ -891,8 +891,18 @@ class FusedTrainStep:
             # ---- reduce + update
             self._reduce_rest(pending)
             if self.deferred is None:
-                self.opt.step_flat(zero_grad=True)                   # step() + zero_grad() in the optimizer's own launch
+                # step() + zero_grad() in the optimizer's own launch — which also carries the step's loss scalars out of the
+                # captured step's static buffer into a fresh tensor (instead of a clone launch)
+                static = out if torch.is_tensor(out) else None
+                if static is not None and os.environ.get('SBR_LOSS_COPY', '1') == '0':      # A/B: clone launch instead
+                    out, static = static.clone().unbind(0), None
+                fresh = torch.empty_like(static) if static is not None else None
+                took = self.opt.step_flat(zero_grad=True, copy=(static, fresh) if static is not None else None)
+                if static is not None:
+                    out = (fresh if took else static.clone()).unbind(0)
             else:
+                if torch.is_tensor(out):
+                    out = out.clone().unbind(0)
                 d, g = self.deferred, self.opt.fp.grad
                 self.opt.step_flat(skip=(d.lo, d.hi))
                 d.update(self._touched_rows if self._sparse else pb.u[:-1])   # also re-zeroes the gradient rows it consumed

@@ -721,10 +721,16 @@ def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, exc
 
 
 # ---- optimizer steps ----------------------------------------------------------------------------------------------------------
-def adam_step(kind: int, p, g, m, v, lr, b1, b2, eps, wd, step: int, zero_grad: bool = False):
-    """One dense Adam / AdamW step; ``zero_grad``: the gradient is reset by the same launch (step() + zero_grad())."""
-    call('sbr_adam_step_zero_grad' if zero_grad else 'sbr_adam_step', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps,
-         wd, step, stream())
+def adam_step(kind: int, p, g, m, v, lr, b1, b2, eps, wd, step: int, zero_grad: bool = False, copy=None):
+    """One dense Adam / AdamW step; ``zero_grad``: the gradient is reset by the same launch (step() + zero_grad());
+    ``copy`` = (src, dst) float64 tensors of <= 256 elements (needs ``zero_grad``): copied by the same launch."""
+    if zero_grad:
+        src, dst = copy if copy is not None else (None, None)
+        call('sbr_adam_step_zero_grad', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, wd, step, ptr(src), ptr(dst),
+             0 if src is None else src.numel(), stream())
+    else:
+        assert copy is None
+        call('sbr_adam_step', kind, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, wd, step, stream())
 
 
 def adagrad_step(p, g, s, lr, eps, wd):

@@ -91,9 +91,10 @@ class FusedOptimizer:
         self._sync_grads()
         self.step_flat()
 
-    def step_flat(self, skip=None, zero_grad: bool = False):
+    def step_flat(self, skip=None, zero_grad: bool = False, copy=None):
         """Update from the flat gradient buffer as it is (the fused step writes gradients there directly). ``zero_grad``: the
-        gradient buffer is reset by the optimizer's own launch (Adam / AdamW; Adagrad zeroes it with a fill).
+        gradient buffer is reset by the optimizer's own launch (Adam / AdamW; Adagrad zeroes it with a fill). ``copy`` = (src, dst)
+        small float64 tensors: copied by that launch too (returns True when it was; Adam / AdamW with ``zero_grad`` only).
         ``skip`` = (lo, hi): leave that range of the flat buffers alone — a lookup table whose rows the fused step updates
         itself, deferred row by row (engine.DeferredTable). A step without ``skip`` first brings such a table up to date."""
         if skip is None and self.deferred is not None:
@@ -104,14 +105,18 @@ class FusedOptimizer:
             ops.adagrad_step(fp.flat, fp.grad, self.m, self.lr, 1e-10, self.wd)
             if zero_grad:
                 fp.grad.zero_()
-            return
+            return False
         kind = 0 if self.name == 'adamw' else 1
+        copied = False
         for lo, hi in ([(0, fp.total)] if skip is None else [(0, skip[0]), (skip[1], fp.total)]):
             if hi > lo:
+                cp = copy if (zero_grad and copy is not None and not copied) else None
                 ops.adam_step(kind, fp.flat[lo:hi], fp.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, 0.9, 0.999, 1e-8,
-                              self.wd, self.step_count, zero_grad=zero_grad)
+                              self.wd, self.step_count, zero_grad=zero_grad, copy=cp)
+                copied = copied or cp is not None
         if skip is None and self.deferred is not None:
             self.deferred.mark_all_current()           # this step updated the table densely
+        return copied
 
     def zero_grad(self):
         self.fp.zero_grad()

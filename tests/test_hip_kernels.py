@@ -310,9 +310,12 @@ def test_adam_step_with_folded_zero_grad(kind):
         p, m, v = _rand(n, seed=1).to(DEV), (_rand(n, seed=2) * 0.1).to(DEV), (_rand(n, seed=3).abs() * 0.01).to(DEV)
         g = g0.clone().to(DEV)
         for step in (1, 2):
-            ops.adam_step(kind, p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, zero_grad=fold)
+            src = torch.tensor([1.5, -2.0, float(step)], device=DEV, dtype=torch.float64)
+            dst = torch.zeros(3, device=DEV, dtype=torch.float64)
+            ops.adam_step(kind, p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, zero_grad=fold, copy=(src, dst) if fold else None)
             if fold:
                 assert bool((g.view(torch.int32) == 0).all())
+                assert torch.equal(dst, src)                     # the small copy that rides on the launch
             g.copy_(g0)
         res[fold] = (p.cpu(), m.cpu(), v.cpu())
     for a, b in zip(res[True], res[False]):
