@@ -155,6 +155,12 @@ int sbr_csr_rows_to_dense(const long* indptr, const int* indices, const float* d
 /* nn.Embedding forward — algorithms/sgd_alg.py:1331,1386: out[oi(j), :] = W[rows[j], :] */
 int sbr_gather_rows(const float* W, long ldw, const int* rows, float* out, long ldo, const int* out_idx, long n, int D,
                     void* stream);
+/* a plain embedding-lookup side in ONE launch (new: the fused training step): sbr_resolve_rows with one segment and k = 1
+ * (data/Feature.py:146: id -> row through rowmap, or the id itself when rowmap is NULL and id < rowmap_len) + sbr_gather_rows;
+ * rows_out [n] keeps the rows for sbr_scatter_add_rows. Ids without a row set *err_flag and read row 0. */
+int sbr_lookup_rows_supported(const float* W, long ldw, const float* out, long ldo, int D);
+int sbr_lookup_rows(const long* idx, long n, const int* rowmap, int rowmap_len, const float* W, long ldw, int* rows_out, float* out,
+                    long ldo, int D, int* err_flag, void* stream);
 /* its dense gradient: dW[rows[j], :] += dOut[ii(j), :] (dW zero-initialised by the caller) */
 int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW, long ldw, long n, int D,
                          void* stream);

@@ -231,6 +231,45 @@ extern "C" int sbr_gather_rows(const float* W, long ldw, const int* rows, float*
   return SBR_OK;
 }
 
+// A plain embedding-lookup side in ONE launch: id -> table row (sbr_resolve_rows with one segment and k = 1) and the row gather
+// (sbr_gather_rows) — out[j, :] = W[row(idx[j]), :], rows_out[j] = row(idx[j]) kept for the backward pass. Every one of the D / 4
+// threads of a row resolves the id itself (one cached load each); ids without a row set *err and read row 0, as sbr_resolve_rows.
+__global__ void lookup_rows4_kernel(const long* __restrict__ idx, long n, const int* __restrict__ rowmap, int map_len,
+                                    const float* __restrict__ W, long ldw, int* __restrict__ rows_out, float* __restrict__ out, long ldo,
+                                    int D4, int* __restrict__ err) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= n * D4) return;
+  const long j = e / D4;
+  const int c4 = (int)(e - j * D4);
+  const long id = idx[j];
+  int r = -1;
+  if (id >= 0 && id < map_len) r = rowmap ? rowmap[id] : (int)id;
+  if (r < 0) {
+    if (c4 == 0) atomicExch(err, 1);
+    r = 0;
+  }
+  if (c4 == 0) rows_out[j] = r;
+  *reinterpret_cast<float4*>(out + j * ldo + 4 * c4) = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * c4);
+}
+
+// 1 when sbr_lookup_rows takes this layout (else: sbr_resolve_rows + sbr_gather_rows)
+extern "C" int sbr_lookup_rows_supported(const float* W, long ldw, const float* out, long ldo, int D) {
+  return (D & 3) == 0 && D >= 4 && (ldw & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)W) | ((uintptr_t)out)) & 15) == 0;
+}
+
+extern "C" int sbr_lookup_rows(const long* idx, long n, const int* rowmap, int rowmap_len, const float* W, long ldw, int* rows_out,
+                               float* out, long ldo, int D, int* err_flag, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(idx && W && rows_out && out && err_flag, "sbr_lookup_rows: null operand");
+  SBR_REQUIRE(sbr_lookup_rows_supported(W, ldw, out, ldo, D), "sbr_lookup_rows: D=%d / alignment not supported", D);
+  const long total4 = n * (D / 4);
+  SBR_REQUIRE(total4 < (1L << 31) * 256, "sbr_lookup_rows: too many rows");
+  lookup_rows4_kernel<<<(unsigned)sbr_cdiv(total4, 256), 256, 0, (hipStream_t)stream>>>(idx, n, rowmap, rowmap_len, W, ldw, rows_out, out,
+                                                                                        ldo, D / 4, err_flag);
+  SBR_CHECK_LAUNCH("sbr_lookup_rows");
+  return SBR_OK;
+}
+
 // backward of the lookup: dW[rows[j], :] += scale * dOut[ii(j), :]   (float atomics into a zero-initialised dense gradient;
 // the reference's dense nn.Embedding gradient, consumed by a dense optimizer — trainer.py:62-68)
 __global__ void scatter_add_rows_kernel(const float* __restrict__ dOut, long ldo, const int* __restrict__ in_idx,

@@ -456,6 +456,18 @@ class _PlainRun:
         n = flat.numel()
         self.n = n
         self.slots = _identity_slots(n, flat.device)
+        if fe.kind == 'categorical' and flat.dtype == torch.int64 and flat.is_contiguous():
+            # embedding lookup: id -> row and the row gather in one launch
+            W = fe.front_params()[0]
+            self.out = a.f32(n, fe.front_dim)
+            if ops.lib().sbr_lookup_rows_supported(ptr(W), W.stride(0), ptr(self.out), self.out.stride(0), int(fe.front_dim)):
+                t = fe._table
+                self.rows = a.i32(n)
+                call('sbr_lookup_rows', ptr(flat), n, ptr(t.rowmap), int(t.rowmap.numel()) if t.rowmap is not None else int(t.n_rows),
+                     ptr(W), W.stride(0), ptr(self.rows), ptr(self.out), self.out.stride(0), int(fe.front_dim), ptr(fe._idx_err),
+                     ops.stream())
+                self.hidden = []
+                return self.out
         self.rows, _ = resolve_rows(flat, 1, self.slots, [0, n], [fe._table], fe._idx_err)
         self.out = a.f32(n, fe.front_dim)
         self.hidden = fe.front_forward(fe.front_params(), self.rows, n, self.out, None)
