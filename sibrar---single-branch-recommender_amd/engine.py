@@ -581,6 +581,7 @@ class FusedTrainStep:
         self.n_replays = 0
         self._up_stream = None
         self._label_cache = {}
+        self.last_out3 = None        # the last step's (total, rec, reg) as ONE float64 [3] tensor (graph replays; else None)
         self._loss_ws = None         # partial sums + arrival counter of the one-launch loss kernel (zeroed once, self-resetting)
         self._tail_ws = None         # the same for the fused scorer + loss + statistics kernel
         self._packed = None
@@ -862,6 +863,7 @@ class FusedTrainStep:
                     if t is not None:
                         t.record_stream(cur)
             self.n_steps += 1
+            self.last_out3 = None
             out = None
             if self._sparse is None:
                 self._setup_sparse_exchange(int(pb.u_shape[0]))
@@ -911,7 +913,8 @@ class FusedTrainStep:
                 fresh = torch.empty_like(static) if static is not None else None
                 took = self.opt.step_flat(zero_grad=True, copy=(static, fresh) if static is not None else None)
                 if static is not None:
-                    out = (fresh if took else static.clone()).unbind(0)
+                    self.last_out3 = fresh if took else static.clone()   # (total, rec, reg) of this step as one [3] tensor
+                    out = self.last_out3.unbind(0)
             else:
                 if torch.is_tensor(out):
                     out = out.clone().unbind(0)

@@ -141,12 +141,17 @@ class Trainer:
         self.model.train()
         sums = {}
         n_batches = self._n_batches_uncapped if self._n_batches_uncapped is not None else len(self.train_loader)
+        acc3 = None                                    # fused step: (loss, rec_loss, reg_loss) accumulated by ONE launch per step
         for batch_count, batch in enumerate(self.train_loader):
             total, rec, regs = self.train_step(*batch)
-            vals = {'loss': total, 'rec_loss': rec, **regs}
-            for k, v in vals.items():
-                v = v.double().sum()
-                sums[k] = v if k not in sums else sums[k] + v
+            out3 = getattr(self.fused, 'last_out3', None) if self.fused is not None else None
+            if out3 is not None and set(regs) == {'reg_loss'}:
+                acc3 = out3.clone() if acc3 is None else acc3.add_(out3)
+            else:
+                vals = {'loss': total, 'rec_loss': rec, **regs}
+                for k, v in vals.items():
+                    v = v.double().sum()
+                    sums[k] = v if k not in sums else sums[k] + v
             if self.max_batches is not None and self.max_batches <= batch_count + 1:
                 print(f'limit of {self.max_batches} batches hit, thus stopping this training cycle.')
                 if hasattr(self.train_loader, 'close'):
@@ -154,6 +159,9 @@ class Trainer:
                 break
         if hasattr(self.pointer_to_model, 'check_index_errors'):
             self.pointer_to_model.check_index_errors()                               # ids without a feature row -> KeyError
+        if acc3 is not None:
+            for k, v in zip(('loss', 'rec_loss', 'reg_loss'), acc3.unbind(0)):
+                sums[k] = v if k not in sums else sums[k] + v
         return {f'train/{k}': float(v) / n_batches for k, v in sums.items()}        # one host sync per epoch
 
     @torch.no_grad()
