@@ -94,6 +94,13 @@ int sbr_gemm_wres_f32(int mode, const float* A, long lda, const float* W, long l
 int sbr_gemm_split_supported(long M, int N, int K);
 int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
                        int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream);
+/* mode 0 with the statistics epilogue and sbr_bn_finalize_stats in ONE launch (new): the last workgroup to arrive turns the pending
+ * sums into save_mean / save_rstd of the M rows of C, updates running_mean / running_var (may both be NULL) and
+ * num_batches_tracked (may be NULL); colsum_ws (zero on entry) and *arrive (one zeroed 64-bit word owned by the BatchNorm) are
+ * left zeroed. */
+int sbr_gemm_split_bnstats_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M, int N,
+                               int K, int act, double* colsum_ws, void* arrive, float* running_mean, float* running_var,
+                               long* num_batches_tracked, float* save_mean, float* save_rstd, float eps, float momentum, void* stream);
 /* The dense modality projector on the same arithmetic — FeatureEmbedding's nn.Linear(F, C) over gathered feature rows
  * (algorithms/sgd_alg.py:1279-1396, forward of 1960-1974): C[ci(m), 0..127] = act(A[ai(m), 0..K-1] x W^T + bias), W [128][K],
  * N = 128, K = 128 j >= 256; a_idx (feature row of every slot), c_idx (row of the shared network's input), bias may be NULL.

@@ -39,6 +39,11 @@ struct SplitArgs {
   int act;
   const float* Y; long ldy;        // EPI 1: C = (A W) * act'(Y)
   double* colsum_ws;                // EPI 1: += column sums of C (replica layout of sbr_col_reduce, K = 1), may be null
+  // EPI 2, optional (fin_mean != null): the workgroup whose arrival comes last turns the pending sums into the BatchNorm's batch
+  // statistics itself (what sbr_bn_finalize_stats does with a launch of its own) and resets the replicas and the counter
+  unsigned long long* fin_arrive;   // zero on entry, zero again on return
+  float* fin_mean; float* fin_rstd; float* fin_running_mean; float* fin_running_var; long* fin_nbt;
+  float fin_eps, fin_momentum;
 };
 
 // MODE 0: NT (W is [n][k]); MODE 1: NN (W is [k][n]). EPI 0: bias + activation; EPI 1: activation derivative of Y + column sums;
@@ -217,6 +222,41 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
       const double o = cs[j] + __shfl_xor(cs[j], 32, 64), q = cq[j] + __shfl_xor(cq[j], 32, 64);
       if (half == 0) { atomicAdd(rep + j * 32 + l31, o); atomicAdd(rep + SP_N + j * 32 + l31, q); }
     }
+    if (g.fin_mean) {
+      // arrival (agent-scope counter; the sums went out as agent-scope atomics: a workgroup-scope release = wait for them)
+      __shared__ int fin_last;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (t == 0) fin_last = atomicAdd(g.fin_arrive, 1ull) == gridDim.x - 1;
+      __syncthreads();
+      if (fin_last && t < SP_N) {
+        // = bn_finalize_kernel (batchnorm.hip): replicas summed in replica order, left zeroed
+        const int KD = 2 * SP_N;
+        double sm = 0.0, sq = 0.0;
+#pragma unroll
+        for (int r = 1; r <= SBR_COLRED_REP; ++r) {
+          sm += __hip_atomic_load(&g.colsum_ws[(long)r * KD + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sq += __hip_atomic_load(&g.colsum_ws[(long)r * KD + SP_N + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g.colsum_ws[(long)r * KD + t] = 0.0;
+          g.colsum_ws[(long)r * KD + SP_N + t] = 0.0;
+        }
+        const double n = (double)g.M;
+        const double m = sm / n;
+        double var = sq / n - m * m;
+        if (var < 0.0) var = 0.0;
+        g.fin_mean[t] = (float)m;
+        g.fin_rstd[t] = (float)(1.0 / sqrt(var + (double)g.fin_eps));
+        if (g.fin_running_mean) {
+          const double unbiased = g.M > 1 ? var * n / (n - 1.0) : var;
+          g.fin_running_mean[t] = (1.f - g.fin_momentum) * g.fin_running_mean[t] + g.fin_momentum * (float)m;
+          g.fin_running_var[t] = (1.f - g.fin_momentum) * g.fin_running_var[t] + g.fin_momentum * (float)unbiased;
+        }
+        if (t == 0) {
+          if (g.fin_nbt) g.fin_nbt[0] += 1;
+          __hip_atomic_store(g.fin_arrive, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   }
   if constexpr (EPI == 1) {
     if (g.colsum_ws) {
@@ -241,8 +281,10 @@ extern "C" int sbr_gemm_split_supported(long M, int N, int K) { return M >= 1 &&
 // contract of sbr_colsum / sbr_colred_finish, may be NULL) receives the pending column sums of C.
 // mode 0 with colsum_ws != NULL (17 * 2 * 128 doubles, zero on entry like every column-reduction workspace): the per-column sums
 // and sums of squares of C are left pending there (sbr_bn_finalize_stats turns them into the statistics of the BatchNorm behind C).
-extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
-                                  long M, int N, int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream) {
+struct SplitFin { unsigned long long* arrive; float *mean, *rstd, *running_mean, *running_var; long* nbt; float eps, momentum; };
+
+static int gemm_split_impl(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
+                           long M, int N, int K, int act, const float* Y, long ldy, double* colsum_ws, const SplitFin* fin, void* stream) {
   SBR_REQUIRE(mode == 0 || mode == 1, "sbr_gemm_split_f32: mode %d", mode);
   if (M == 0) return SBR_OK;
   SBR_REQUIRE(sbr_gemm_split_supported(M, N, K), "sbr_gemm_split_f32: shape %ld x %d x %d not supported (N = K = 128)", M, N, K);
@@ -252,6 +294,9 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
   SplitArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.act = act; g.Y = Y; g.ldy = ldy;
   g.colsum_ws = colsum_ws;
+  g.fin_arrive = fin ? fin->arrive : nullptr; g.fin_mean = fin ? fin->mean : nullptr; g.fin_rstd = fin ? fin->rstd : nullptr;
+  g.fin_running_mean = fin ? fin->running_mean : nullptr; g.fin_running_var = fin ? fin->running_var : nullptr;
+  g.fin_nbt = fin ? fin->nbt : nullptr; g.fin_eps = fin ? fin->eps : 0.f; g.fin_momentum = fin ? fin->momentum : 0.f;
   const int n_blocks = sbr_cdiv(M, 32);
   int grid = sbr_cdiv(n_blocks, SP_WAVES);
   if (grid > 256) grid = 256;
@@ -276,6 +321,24 @@ extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const floa
 #undef SP_LAUNCH
   SBR_CHECK_LAUNCH("sbr_gemm_split_f32");
   return SBR_OK;
+}
+
+extern "C" int sbr_gemm_split_f32(int mode, const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
+                                  long M, int N, int K, int act, const float* Y, long ldy, double* colsum_ws, void* stream) {
+  return gemm_split_impl(mode, A, lda, W, ldw, bias, C, ldc, M, N, K, act, Y, ldy, colsum_ws, nullptr, stream);
+}
+
+// mode 0 with the statistics epilogue AND the BatchNorm finalisation (sbr_bn_finalize_stats) in the same launch: the workgroup that
+// arrives last computes save_mean / save_rstd of the M rows of C, updates the running statistics (may be NULL) and
+// num_batches_tracked (may be NULL) and leaves colsum_ws and *arrive (one zeroed 64-bit word, owned by the BatchNorm) zeroed.
+extern "C" int sbr_gemm_split_bnstats_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, long M,
+                                          int N, int K, int act, double* colsum_ws, void* arrive, float* running_mean,
+                                          float* running_var, long* num_batches_tracked, float* save_mean, float* save_rstd, float eps,
+                                          float momentum, void* stream) {
+  SBR_REQUIRE(colsum_ws && arrive && save_mean && save_rstd && M >= 1, "sbr_gemm_split_bnstats_f32: null operand");
+  SBR_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sbr_gemm_split_bnstats_f32: running_mean and running_var go together");
+  SplitFin fin = {(unsigned long long*)arrive, save_mean, save_rstd, running_mean, running_var, num_batches_tracked, eps, momentum};
+  return gemm_split_impl(0, A, lda, W, ldw, bias, C, ldc, M, N, K, act, nullptr, 0, colsum_ws, &fin, stream);
 }
 
 // =====================================================================================================================

@@ -212,7 +212,12 @@ class _EntityRun:
             if bn is None:
                 out_l = a.f32(R, w.shape[0])
                 if tail_stats and li == len(self.layers) - 1 and ops.linear_nt_stats_ok(x, w, out_l):
-                    y = ops.linear_nt(x, w, lin.bias, act, out=out_l, stats_ws=self._bn_ws(self.trailing, w.shape[0]))
+                    # ... and the BatchNorm's finalisation (batch mean / rstd, running statistics) by the GEMM's last workgroup
+                    bn = self.trailing
+                    self._fin = (a.f32(w.shape[0]), a.f32(w.shape[0]))
+                    y = ops.linear_nt(x, w, lin.bias, act, out=out_l, stats_ws=self._bn_ws(bn, w.shape[0]),
+                                      bn_fin=(self._bn_arrive(bn), bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                              self._fin[0], self._fin[1], ops.BN_EPS, ops.BN_MOMENTUM))
                     self._stats_folded = True
                 else:
                     y = ops.linear_nt(x, w, lin.bias, act, out=out_l)
@@ -228,11 +233,10 @@ class _EntityRun:
             if self.fuse_tail and k == 1 and not self.reg and ops.lib().sbr_bn_score_supported(int(x.shape[1])):
                 # statistics only: the scorer normalises on the fly (FusedTrainStep._phase1), nothing else reads the output
                 bn, n_, D_ = self.trailing, x.shape[0], x.shape[1]
-                mean, rstd = a.f32(D_), a.f32(D_)
                 if self._stats_folded:
-                    call('sbr_bn_finalize_stats', n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
-                         ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
+                    mean, rstd = self._fin                 # written by the last workgroup of the GEMM in front (no launch here)
                 else:
+                    mean, rstd = a.f32(D_), a.f32(D_)
                     call('sbr_bn_train_stats', ptr(x), n_, D_, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
                          ptr(mean), ptr(rstd), ptr(self._bn_ws(bn, D_)), ops.BN_EPS, ops.BN_MOMENTUM, st)
                 self.tail = (x, mean, rstd)
@@ -261,6 +265,15 @@ class _EntityRun:
         self.arg = a.u8(S, self.D) if ent._agg_mode == 1 else None
         call('sbr_aggregate_fwd', ptr(x), ptr(out), ptr(self.arg), S, k, self.D, ent._agg_mode, st)
         return out
+
+    def _bn_arrive(self, bn):
+        """Persistent zeroed int64[1] of one BatchNorm: the arrival counter of the GEMM that finalises its statistics."""
+        c = self._ws.get(('arrive', id(bn)))
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the BatchNorm arrival counter must exist before a step is captured (run one plain step first)')
+            c = self._ws[('arrive', id(bn))] = torch.zeros(1, device=bn.weight.device, dtype=torch.int64)
+        return c
 
     def _bn_ws(self, bn, D):
         """Persistent column-reduction workspace of one BatchNorm (zero on first use, left zeroed by every kernel pair)."""

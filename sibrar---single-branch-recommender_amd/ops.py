@@ -106,10 +106,12 @@ def linear_nt_stats_ok(x, W, out) -> bool:
     return _wres_ok(M, N, K, x, W, out) and _mlp_kernel(M, N, K) == 'sbr_gemm_split_f32'
 
 
-def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None, stats_ws=None):
+def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=None, stats_ws=None, bn_fin=None):
     """out[ci(m)] = act(x[ai(m)] @ W^T + bias). W: [N, K] with arbitrary row stride (column-major weights are handled by
     the caller through csr kernels, not here). ``stats_ws`` (check ``linear_nt_stats_ok`` first): a zeroed column-reduction
-    workspace of 17 * 2 * N doubles that receives the per-column sums and sums of squares of ``out`` (``bn_finalize_stats``)."""
+    workspace of 17 * 2 * N doubles that receives the per-column sums and sums of squares of ``out`` (``bn_finalize_stats``).
+    ``bn_fin`` (with ``stats_ws``) = (arrive, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, eps, momentum):
+    the same launch also finalises the BatchNorm statistics (``arrive``: a zeroed int64[1] owned by the BatchNorm)."""
     M = n_rows if n_rows is not None else (a_idx.numel() if a_idx is not None else x.shape[0])
     N, K = W.shape
     if out is None:
@@ -118,6 +120,15 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
         kern = _mlp_kernel(M, N, K)
         if stats_ws is not None and kern != 'sbr_gemm_split_f32':
             raise ValueError('linear_nt(stats_ws=...): this product does not take the kernel with the statistics epilogue')
+        if bn_fin is not None:
+            if stats_ws is None:
+                raise ValueError('linear_nt(bn_fin=...) needs stats_ws')
+            arrive, rm, rv, nbt, mean, rstd, eps, mom = bn_fin
+            _timed(('gemm_f32', 0, M, N, K, False),
+                   lambda: call('sbr_gemm_split_bnstats_f32', ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0),
+                                M, N, K, act, ptr(stats_ws), ptr(arrive), ptr(rm), ptr(rv), ptr(nbt), ptr(mean), ptr(rstd), eps, mom,
+                                stream()))
+            return out
         _timed(('gemm_f32', 0, M, N, K, False),
                lambda: call(kern, 0, ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
                             act, None, 0, ptr(stats_ws), stream()))

@@ -1080,3 +1080,15 @@ def test_split_gemm_statistics_epilogue_feeds_batchnorm(M, act, monkeypatch):
     for a_, b_, what in zip(res['folded'], res['own pass'], ('mean', 'rstd', 'running mean', 'running var', 'batches')):
         close(a_.double(), b_.double(), rtol=1e-6, atol=1e-7, what=what)
     assert float(ws[2 * 128:].abs().max()) == 0.0                # replicas left zeroed for the next use
+    # the finalisation by the GEMM's last workgroup (bn_fin): one launch, the bits of the two above, workspace and counter left zeroed,
+    # a second call on the same workspace / counter the same again
+    arrive = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for rep in range(2):
+        rm, rv, nbt = torch.zeros(128, device=DEV), torch.ones(128, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        mean, rstd = torch.empty(128, device=DEV), torch.empty(128, device=DEV)
+        out2 = torch.empty(M, 128, device=DEV)
+        ops.linear_nt(x, w, b, act, out=out2, stats_ws=ws, bn_fin=(arrive, rm, rv, nbt, mean, rstd, ops.BN_EPS, ops.BN_MOMENTUM))
+        assert torch.equal(out2, plain)
+        for a_, b_, what in zip((mean, rstd, rm, rv, nbt), res['folded'], ('mean', 'rstd', 'running mean', 'running var', 'batches')):
+            assert torch.equal(a_.cpu(), b_), what
+        assert float(ws[2 * 128:].abs().max()) == 0.0 and int(arrive.item()) == 0
