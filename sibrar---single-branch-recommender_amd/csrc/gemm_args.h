@@ -38,3 +38,7 @@ int sbr_tn_direct_launch(const float* A, long lda, const int* a_idx, const float
 int sbr_tn_split_splits(int M, int N, int K);
 int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                         float* slab, int* splits_out, hipStream_t s);
+// several products in one launch (all must be eligible for the bf16-split kernel; -1 otherwise, nothing launched)
+int sbr_tn_split_launch_multi(int count, const float* const* A, const long* lda, const int* const* a_idx, const float* const* B,
+                              const long* ldb, const int* const* b_idx, const int* M, const int* N, const int* K, float* const* slab,
+                              const long* slab_bytes, int* splits_out, hipStream_t s);

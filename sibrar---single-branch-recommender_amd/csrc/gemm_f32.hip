@@ -516,6 +516,29 @@ extern "C" int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx,
   return tn_slabs(A, lda, a_idx, B, ldb, b_idx, M, N, K, workspace, workspace_bytes, splits_out, (hipStream_t)stream);
 }
 
+// Several deferred products in one call: ONE grouped launch when every product takes the bf16-split kernel (the dW products of the
+// training step), else one launch each — the results are the same slabs either way. All arrays are HOST arrays of `count` entries.
+extern "C" int sbr_gemm_tn_f32_slabs_multi(int count, const void* const* A, const long* lda, const void* const* a_idx, const void* const* B,
+                                           const long* ldb, const void* const* b_idx, const int* M, const int* N, const int* K,
+                                           const void* const* workspaces, const long* workspace_bytes, int* splits_out, void* stream) {
+  SBR_REQUIRE(count >= 1 && count <= 8 && A && lda && a_idx && B && ldb && b_idx && M && N && K && workspaces && workspace_bytes && splits_out,
+              "sbr_gemm_tn_f32_slabs_multi: 1..8 products per call");
+  for (int q = 0; q < count; ++q)
+    SBR_REQUIRE(A[q] && B[q] && workspaces[q] && M[q] >= 1 && N[q] >= 1 && K[q] >= 1, "sbr_gemm_tn_f32_slabs_multi: bad entry %d", q);
+  hipStream_t s = (hipStream_t)stream;
+  if (count >= 2 && count <= 4) {
+    const int rc = sbr_tn_split_launch_multi(count, (const float* const*)A, lda, (const int* const*)a_idx, (const float* const*)B, ldb,
+                                             (const int* const*)b_idx, M, N, K, (float* const*)workspaces, workspace_bytes, splits_out, s);
+    if (rc >= 0) return rc;
+  }
+  for (int q = 0; q < count; ++q) {
+    const int rc = tn_slabs((const float*)A[q], lda[q], (const int*)a_idx[q], (const float*)B[q], ldb[q], (const int*)b_idx[q], M[q], N[q],
+                            K[q], (void*)workspaces[q], workspace_bytes[q], &splits_out[q], s);
+    if (rc) return rc;
+  }
+  return SBR_OK;
+}
+
 struct SplitkMulti {
   const float* slab[8];
   float* C[8];

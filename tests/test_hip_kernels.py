@@ -972,6 +972,39 @@ def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(M, N, K, gather, monkeyp
 
 
 @pytest.mark.gpu
+def test_deferred_dw_products_go_out_as_one_grouped_launch():
+    """DeferredTN(group=True): the slab launches of the queued products wait for finish() and leave as ONE grouped launch of the
+    bf16-split kernel (sbr_gemm_tn_f32_slabs_multi) — the bits of one launch per product (group=False): the c2 step's three dW
+    shapes (128 x 128 twice, 128 x 768 row-gathered), a mixed call in which one product is not eligible (K < 4096: every product
+    then takes its own launch), and five products (two grouped launches)."""
+    ops = S().ops
+    g = torch.Generator().manual_seed(3)
+    dz1, h1 = _rand(90112, 128, seed=11).to(DEV), _rand(90112, 128, seed=12).to(DEV)
+    dz2, x0 = _rand(90112, 128, seed=13).to(DEV), _rand(90112, 128, seed=14).to(DEV)
+    dzp, X = _rand(45824, 128, seed=15).to(DEV), _rand(5000, 768, seed=16).to(DEV)
+    rows = torch.randint(0, 5000, (45824,), generator=g, dtype=torch.int32).to(DEV)
+    small_a, small_b = _rand(3000, 128, seed=17).to(DEV), _rand(3000, 128, seed=18).to(DEV)
+    cases = {'c2': [(dz1, h1, None, None), (dz2, x0, None, None), (dzp, X, rows, 45824)],
+             'mixed': [(dz1, h1, None, None), (small_a, small_b, None, None), (dzp, X, rows, 45824)],
+             'five': [(dz1, h1, None, None), (dz2, x0, None, None), (dzp, X, rows, 45824), (dz2, h1, None, None), (dz1, x0, None, None)]}
+    for name, prods in cases.items():
+        res = {}
+        for group in (True, False):
+            d = ops.DeferredTN(group=group)
+            outs = []
+            for q, (a, b, bi, n) in enumerate(prods):
+                o = torch.empty(128, b.shape[1], device=DEV)
+                d.matmul_tn(('k', q), a, b, b_idx=bi, n_rows=n, out=o)
+                outs.append(o)
+            assert len(d.queued) == (len(prods) if group else 0)
+            d.finish()
+            assert not d.queued and not d.pending
+            res[group] = [o.clone() for o in outs]
+        for a, b in zip(res[True], res[False]):
+            assert torch.equal(a, b), name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n_fin', [1, 3, 8])
 def test_slab_reducer_also_finishes_pending_column_sums(n_fin):
     """DeferredTN.finish(colred) = sbr_splitk_reduce_multi_fin: one launch sums the split-K slabs of the pending dW products AND turns
