@@ -68,12 +68,6 @@ int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, 
  * arrays of device pointers; ldcs / Ms / Ns / splits: HOST arrays. */
 int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                           void* workspace, long workspace_bytes, int* splits_out, void* stream);
-/* several deferred products in one call (HOST arrays of `count` <= 8 entries): ONE grouped launch when every product takes the
- * bf16-split kernel (2 - 4 products: the dW products of a training step, launched together when the backward pass is over), else
- * one launch per product; splits_out[q] (host) receives product q's slab count. */
-int sbr_gemm_tn_f32_slabs_multi(int count, const void* const* A, const long* lda, const void* const* a_idx, const void* const* B,
-                                const long* ldb, const void* const* b_idx, const int* M, const int* N, const int* K,
-                                const void* const* workspaces, const long* workspace_bytes, int* splits_out, void* stream);
 int sbr_splitk_reduce_multi(int count, const void* const* slabs, const void* const* outs, const long* ldcs, const int* Ms, const int* Ns,
                             const int* splits, void* stream);
 /* the same launch also finishes up to 8 pending column reductions (sbr_colred_finish: out[i] = sum of the replicas of entry i of

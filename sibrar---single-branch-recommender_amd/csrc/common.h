@@ -76,6 +76,14 @@ __device__ __forceinline__ float sbr_wave_max(float v) {
   return v;
 }
 
+// "This wave's vector-memory operations have been performed" — the wait an agent-scope hand-off needs in front of the workgroup
+// barrier that precedes an arrival-counter add (MI355X_MICROARCH.md, Valid forms: every storing wave's s_waitcnt vmcnt(0), the
+// barrier, then the counter). Stores and no-return atomics count in vmcnt on gfx950. A workgroup-scope release fence does NOT emit
+// this wait (checked in the disassembly: the counter add followed the sum atomics with only lgkmcnt(0) + s_barrier in between), and
+// inline asm is invisible to the compiler's wait-count pass, so it cannot be dropped. tools/check_arrival_waits.py greps the built
+// kernels for it.
+#define SBR_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 static inline int sbr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 
@@ -158,8 +166,7 @@ static __global__ void sbr_colred_final_kernel(double* __restrict__ ws, int KD) 
 static inline int sbr_col_reduce_blocks(long n, int D) {
   const int RL = 256 / (D >> 2);
   long b = (n + 8L * RL - 1) / (8L * RL);
-  static long cap = 0;
-  if (cap == 0) cap = getenv("SBR_COLRED_BLOCKS") ? atol(getenv("SBR_COLRED_BLOCKS")) : 512;
+  const long cap = 512;
   if (b > cap) b = cap;          // one double atomic per block and column: more blocks only add contention on D addresses
   return b < 1 ? 1 : (int)b;
 }

@@ -276,14 +276,15 @@ __global__ __launch_bounds__(256) void bn_score_loss_kernel(const float* __restr
     }
   }
   // ---- arrival: the last block finishes the loss and the column sums. Everything another block has to see went out as an
-  // agent-scope atomic (performed at the memory side), so "release" only has to WAIT for this block's atomics (a workgroup-scope
-  // fence = s_waitcnt): __threadfence() writes the XCD's whole L2 back — per block, with the dU / dlogits lines of every block in
-  // it — and made this kernel's time grow with the number of blocks (120 us at 1,024 blocks, 75 at 512).
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // agent-scope atomic (performed at the memory side), so "release" only has to WAIT for this block's atomics (an explicit
+  // s_waitcnt vmcnt(0) per wave: a workgroup-scope fence does not emit it): __threadfence() writes the XCD's whole L2 back — per
+  // block, with the dU / dlogits lines of every block in it — and made this kernel's time grow with the number of blocks (120 us at
+  // 1,024 blocks, 75 at 512).
+  SBR_DRAIN_VMEM();
   __syncthreads();                                               // every thread's atomics have been performed
   if (t == 0) {
     __hip_atomic_store(&lws[1 + blockIdx.x], lsum * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    SBR_DRAIN_VMEM();                                            // the partial sum has been performed before the counter moves
     const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long*>(lws), 1ull);
     last_flag = before == gridDim.x - 1;
   }
@@ -425,7 +426,7 @@ extern "C" int sbr_bn_score_bwd_stats(const float* G, const float* U, const floa
   hipStream_t s = (hipStream_t)stream;
   const int RL = 256 / (D >> 2);
   long blocks = (B + 2L * RL - 1) / (2L * RL);               // >= 2 users per row lane
-  { const long cap = getenv("SBR_COLRED_BLOCKS") ? atol(getenv("SBR_COLRED_BLOCKS")) : 512; if (blocks > cap) blocks = cap; }
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   bn_score_bwd_stats_kernel<<<(int)blocks, 256, 0, s>>>(G, U, Z, dU, B, N, D, save_mean, save_rstd, weight, bias, ws);
   SBR_CHECK_LAUNCH("sbr_bn_score_bwd_stats");

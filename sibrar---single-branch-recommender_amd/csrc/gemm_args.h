@@ -27,18 +27,8 @@ struct GemmArgs {
 // kernel.
 int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s);
 
-// gemm_tn_direct_f32.hip: weight-gradient products (M = 128, N = 128 j, long K) straight from global memory, one slab per workgroup.
-// sbr_tn_direct_splits: slabs it would write (0: shape not eligible); sbr_tn_direct_launch returns -1 when not eligible.
-int sbr_tn_direct_splits(const float* A, long lda, int M, int N, int K);
-int sbr_tn_direct_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
-                         float* slab, int* splits_out, hipStream_t s);
-
-// gemm_split_tn_f32.hip: the same products on the bf16 matrix pipe (exact three-way split of both operands, six MFMA terms), one slab
+// gemm_split_tn_f32.hip: weight-gradient products (M = 128 i, N = 128 j, long K) on the bf16 matrix pipe (exact three-way split of both operands, six MFMA terms), one slab
 // per workgroup. sbr_tn_split_splits: slabs it would write (0: shape not eligible or SBR_GEMM_SPLIT=0 / SBR_TN_SPLIT=0).
 int sbr_tn_split_splits(int M, int N, int K);
 int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                         float* slab, int* splits_out, hipStream_t s);
-// several products in one launch (all must be eligible for the bf16-split kernel; -1 otherwise, nothing launched)
-int sbr_tn_split_launch_multi(int count, const float* const* A, const long* lda, const int* const* a_idx, const float* const* B,
-                              const long* ldb, const int* const* b_idx, const int* M, const int* N, const int* K, float* const* slab,
-                              const long* slab_bytes, int* splits_out, hipStream_t s);

@@ -391,7 +391,6 @@ static int nt_splits(int M, int N, int K) {
   int splits = (int)((192 + tiles - 1) / tiles);            // aim at ~192 work items
   const int max_splits = K / (4 * BK);                      // at least 4 slabs per item
   if (splits > max_splits) splits = max_splits;
-  if (getenv("SBR_NT_SPLITS")) splits = atoi(getenv("SBR_NT_SPLITS"));      // tuning aid (0 / 1 = off)
   return splits < 2 ? 1 : splits;
 }
 
@@ -440,15 +439,12 @@ static int tn_splits(int M, int N, int K) {
   int splits = want < max_splits ? want : max_splits;
   const int min_splits = sbr_cdiv(K, 512);             // the ring kernel stages <= 512 gathered k-row indices per item
   if (splits < min_splits) splits = min_splits;
-  if (getenv("SBR_TN_SPLITS") && atoi(getenv("SBR_TN_SPLITS")) > 0) splits = atoi(getenv("SBR_TN_SPLITS"));   // tuning aid
   return splits < 1 ? 1 : splits;
 }
 
 extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
   int splits = tn_splits(M, N, K);
-  const int ds = sbr_tn_direct_splits(nullptr, 0, M, N, K);           // the opt-in direct kernel cuts K its own way
-  if (ds > splits) splits = ds;
-  const int ss = sbr_tn_split_splits(M, N, K);                         // so does the bf16-split kernel
+  const int ss = sbr_tn_split_splits(M, N, K);                         // the bf16-split kernel cuts K its own way
   if (ss > splits) splits = ss;
   return (long)splits * M * N * (long)sizeof(float);
 }
@@ -463,14 +459,6 @@ static int tn_slabs(const float* A, long lda, const int* a_idx, const float* B, 
     const int ss = sbr_tn_split_splits(M, N, K);
     if (ss > 0 && (long)ss * M * N * (long)sizeof(float) <= workspace_bytes) {
       const int rc = sbr_tn_split_launch(A, lda, a_idx, B, ldb, b_idx, M, N, K, (float*)workspace, splits_out, s);
-      if (rc >= 0) return rc;
-    }
-  }
-  {
-    // opt-in experiment: operands straight from global memory into the fp32 MFMAs, one slab per workgroup
-    const int ds = sbr_tn_direct_splits(A, lda, M, N, K);
-    if (ds > 0 && (long)ds * M * N * (long)sizeof(float) <= workspace_bytes) {
-      const int rc = sbr_tn_direct_launch(A, lda, a_idx, B, ldb, b_idx, M, N, K, (float*)workspace, splits_out, s);
       if (rc >= 0) return rc;
     }
   }
@@ -514,29 +502,6 @@ extern "C" int sbr_gemm_tn_f32_slabs(const float* A, long lda, const int* a_idx,
   SBR_REQUIRE(M >= 1 && N >= 1 && K >= 1 && splits_out, "sbr_gemm_tn_f32_slabs: bad arguments");
   SBR_REQUIRE(A && B, "sbr_gemm_tn_f32_slabs: null operand");
   return tn_slabs(A, lda, a_idx, B, ldb, b_idx, M, N, K, workspace, workspace_bytes, splits_out, (hipStream_t)stream);
-}
-
-// Several deferred products in one call: ONE grouped launch when every product takes the bf16-split kernel (the dW products of the
-// training step), else one launch each — the results are the same slabs either way. All arrays are HOST arrays of `count` entries.
-extern "C" int sbr_gemm_tn_f32_slabs_multi(int count, const void* const* A, const long* lda, const void* const* a_idx, const void* const* B,
-                                           const long* ldb, const void* const* b_idx, const int* M, const int* N, const int* K,
-                                           const void* const* workspaces, const long* workspace_bytes, int* splits_out, void* stream) {
-  SBR_REQUIRE(count >= 1 && count <= 8 && A && lda && a_idx && B && ldb && b_idx && M && N && K && workspaces && workspace_bytes && splits_out,
-              "sbr_gemm_tn_f32_slabs_multi: 1..8 products per call");
-  for (int q = 0; q < count; ++q)
-    SBR_REQUIRE(A[q] && B[q] && workspaces[q] && M[q] >= 1 && N[q] >= 1 && K[q] >= 1, "sbr_gemm_tn_f32_slabs_multi: bad entry %d", q);
-  hipStream_t s = (hipStream_t)stream;
-  if (count >= 2 && count <= 4) {
-    const int rc = sbr_tn_split_launch_multi(count, (const float* const*)A, lda, (const int* const*)a_idx, (const float* const*)B, ldb,
-                                             (const int* const*)b_idx, M, N, K, (float* const*)workspaces, workspace_bytes, splits_out, s);
-    if (rc >= 0) return rc;
-  }
-  for (int q = 0; q < count; ++q) {
-    const int rc = tn_slabs((const float*)A[q], lda[q], (const int*)a_idx[q], (const float*)B[q], ldb[q], (const int*)b_idx[q], M[q], N[q],
-                            K[q], (void*)workspaces[q], workspace_bytes[q], &splits_out[q], s);
-    if (rc) return rc;
-  }
-  return SBR_OK;
 }
 
 struct SplitkMulti {

@@ -414,7 +414,6 @@ static int ring_launch(GemmArgs& g, hipStream_t s) {
 static inline bool ring_al16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
 int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s) {
-  if (getenv("SBR_GEMM_RING") && atoi(getenv("SBR_GEMM_RING")) == 0) return -1;
   if (!ring_al16(g.A, g.lda) || !ring_al16(g.B, g.ldb)) return -1;
   if (g.k_chunk % RK != 0 || g.k_chunk <= 0) return -1;
   const bool a_km = mode == 2, b_kn = mode != 0;
@@ -435,7 +434,6 @@ int sbr_gemm_ring_launch(int mode, GemmArgs& g, hipStream_t s) {
   // only 352 such tiles and stays on 64 x 128 (94 vs 112 us). TN stays on 64 x 128 (the split count provides the items).
   const long big_items = (long)sbr_cdiv(g.M, 128) * sbr_cdiv(g.N, 128);
   int big = mode != 2 && big_items >= 640;
-  if (getenv("SBR_RING_MI")) big = atoi(getenv("SBR_RING_MI")) == 2;       // tuning aid
   if (big) {
     if (mode == 0) return ring_launch<2, false, false, 2>(g, s);
     if (mode == 1) return ring_launch<2, false, true, 2>(g, s);

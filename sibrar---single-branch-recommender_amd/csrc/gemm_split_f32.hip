@@ -223,9 +223,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
       if (half == 0) { atomicAdd(rep + j * 32 + l31, o); atomicAdd(rep + SP_N + j * 32 + l31, q); }
     }
     if (g.fin_mean) {
-      // arrival (agent-scope counter; the sums went out as agent-scope atomics: a workgroup-scope release = wait for them)
+      // arrival (agent-scope counter; the sums went out as agent-scope atomics, performed at the memory side: every wave waits
+      // for its own to be performed, then the barrier, then the counter add — no L2 write-back needed)
       __shared__ int fin_last;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      SBR_DRAIN_VMEM();
       __syncthreads();
       if (t == 0) fin_last = atomicAdd(g.fin_arrive, 1ull) == gridDim.x - 1;
       __syncthreads();

@@ -64,7 +64,7 @@ typedef const __attribute__((address_space(1))) sp_f32x2* ts_gptr;      // row p
 // WIDE: more than one 128 x 128 output tile per K range. The two forms differ only in the workgroup map — and in their symbol,
 // which keeps the step's 128 x 128 and 128 x 768 products apart in a kernel trace.
 // bid / W: this workgroup's index among the W (a multiple of 8) workgroups of its product — the whole grid of
-// gemm_split_tn_kernel, a slice of it in gemm_split_tn_multi_kernel
+// gemm_split_tn_kernel
 template <bool WIDE>
 __device__ __forceinline__ void ts_body(const TnSplitArgs& g, const int bid, const int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -337,20 +337,6 @@ __global__ __launch_bounds__(512, 1) void gemm_split_tn_kernel(TnSplitArgs g) {
 // live in the step's arena until then): workgroups start[p] .. start[p + 1] - 1 (each range a multiple of 8 long, so the XCD
 // round-robin of the whole grid is the round-robin of every slice) belong to product p. Two launch floors and two ramp-up /
 // drain phases per step less than three launches of gemm_split_tn_kernel.
-#define TS_MULTI_MAX 4
-struct TnMulti {
-  TnSplitArgs g[TS_MULTI_MAX];
-  int start[TS_MULTI_MAX + 1];
-  int count;
-};
-__global__ __launch_bounds__(512, 1) void gemm_split_tn_multi_kernel(TnMulti m) {
-  int p = 0;
-#pragma unroll
-  for (int q = 1; q < TS_MULTI_MAX; ++q)
-    if (q < m.count && (int)blockIdx.x >= m.start[q]) p = q;
-  ts_body<true>(m.g[p], (int)blockIdx.x - m.start[p], m.start[p + 1] - m.start[p]);
-}
-
 static bool ts_enabled() {          // read per call: tests and A/B runs switch it within one process
   const char* a = getenv("SBR_GEMM_SPLIT");
   const char* b = getenv("SBR_TN_SPLIT");
@@ -397,39 +383,5 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
 #undef TS_LAUNCH
   SBR_CHECK_LAUNCH("sbr_gemm_tn_f32 (bf16 split)");
   *splits_out = nz;
-  return SBR_OK;
-}
-
-// count (2 .. TS_MULTI_MAX) products in one launch; every one must be eligible (sbr_tn_split_splits > 0, aligned operands) — returns -1
-// otherwise and launches nothing. slab[q]: the product's own workspace, splits_out[q]: its slab count.
-int sbr_tn_split_launch_multi(int count, const float* const* A, const long* lda, const int* const* a_idx, const float* const* B,
-                              const long* ldb, const int* const* b_idx, const int* M, const int* N, const int* K, float* const* slab,
-                              const long* slab_bytes, int* splits_out, hipStream_t s) {
-  if (count < 2 || count > TS_MULTI_MAX) return -1;
-  TnMulti m;
-  m.count = count;
-  m.start[0] = 0;
-  for (int q = 0; q < count; ++q) {
-    const int nz = sbr_tn_split_splits(M[q], N[q], K[q]);
-    if (nz <= 0 || (long)nz * M[q] * N[q] * (long)sizeof(float) > slab_bytes[q]) return -1;
-    if (((uintptr_t)A[q] | (uintptr_t)B[q]) % 8 != 0 || (uintptr_t)slab[q] % 16 != 0 || lda[q] % 2 != 0 || ldb[q] % 2 != 0) return -1;
-    TnSplitArgs& g = m.g[q];
-    g.A = A[q]; g.lda = lda[q]; g.a_idx = a_idx[q]; g.B = B[q]; g.ldb = ldb[q]; g.b_idx = b_idx[q]; g.slab = slab[q];
-    g.M = M[q]; g.N = N[q]; g.K = K[q]; g.nz = nz; g.nj = N[q] / 128; g.nm = M[q] / 128; g.chunks = sbr_cdiv(K[q], TS_KC);
-    m.start[q + 1] = m.start[q] + sbr_cdiv(nz * g.nj * g.nm, 8) * 8;
-    splits_out[q] = nz;
-  }
-  for (int q = count; q < TS_MULTI_MAX; ++q) m.start[q + 1] = m.start[count];
-  const size_t lds = TS_SALU ? 2 * 128 * 128 * sizeof(float) : 2 * TS_BUF + 2 * TS_MAXROWS * sizeof(unsigned long long);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_split_tn_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      sbr_set_error("sbr_gemm_tn_f32: cannot raise the dynamic LDS limit of the bf16-split kernel");
-      return SBR_ERR_HIP;
-    }
-    attr_set = true;
-  }
-  gemm_split_tn_multi_kernel<<<m.start[count], 512, lds, s>>>(m);
-  SBR_CHECK_LAUNCH("sbr_gemm_tn_f32 (bf16 split, grouped)");
   return SBR_OK;
 }

@@ -70,7 +70,7 @@ __global__ void rec_loss_kernel(int kind, const float* __restrict__ logits, cons
       __shared__ int last;
       if (threadIdx.x == 0) {
         __hip_atomic_store(&ws[1 + blockIdx.x], t * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the store has been performed (no L2 write-back: see fused_tail.hip)
+        SBR_DRAIN_VMEM();                                        // the store has been performed (no L2 write-back: see fused_tail.hip)
         const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull);
         last = before == gridDim.x - 1;                          // every other block's partial is out
       }

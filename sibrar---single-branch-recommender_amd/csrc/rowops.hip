@@ -332,157 +332,11 @@ __global__ __launch_bounds__(256) void scatter_add_rows128_kernel(const float* _
   }
 }
 
-// D = 128, 4,096 - 131,072 rows, NO float atomics: every workgroup OWNS the table rows r with r mod G = its index (G = 256
-// workgroups of 16 waves). Each wave scans a sixteenth of the (slot -> table row) list (the whole list is 183 KB at the bench's
-// batch: it is read from L2 by every workgroup) and keeps the entries its workgroup owns, in slot order (wave ballots, no barrier);
-// the sixteen sub-lists are concatenated (still slot order). Then wave w takes list entries w, w + 16, ... six at a time: the
-// gradient row and the table row of all six are requested first, then an entry that is the FIRST of its table row in the list adds
-// its own gradient row and those of the later entries with the same table row, in list order, to the table row it has read and
-// stores it with a plain store — nobody else touches that row during the launch. The sum has a fixed order (table value, then the
-// slots in ascending order): the same bits on every run, which float atomics do not give, and no read-modify-write at the
-// memory-side atomic units (45,824 x 128 floats: 43 us = 0.55 TB/s with atomics).
-// A sub-list holds SO_CAPW entries per wave; further entries of a wave (a table row drawn hundreds of times in one batch) are added
-// with float atomics by the owning workgroup after its plain stores have been fenced.
-#define SO_WAVES 16
-#define SO_CAPW 64
-#define SO_SCAN 8
-#define SO_BATCH 6
-__global__ __launch_bounds__(64 * SO_WAVES) void scatter_add_rows_owned_kernel(const float* __restrict__ dOut, long ldo,
-                                                                               const int* __restrict__ in_idx, const int* __restrict__ rows,
-                                                                               float* __restrict__ dW, long ldw, long n) {
-  __shared__ int w_row[SO_WAVES][SO_CAPW], w_src[SO_WAVES][SO_CAPW];
-  __shared__ int l_row[SO_WAVES * SO_CAPW], l_src[SO_WAVES * SO_CAPW];
-  __shared__ int w_cnt[SO_WAVES];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gmask = gridDim.x - 1, me = blockIdx.x;
-  const unsigned long long lt = (1ull << lane) - 1;
-
-  // ---- scan: the wave's sixteenth of the list
-  const long per = (n + SO_WAVES - 1) / SO_WAVES;
-  const long lo = wave * per, hi = lo + per < n ? lo + per : n;
-  int cnt = 0;
-  for (long b0 = lo; b0 < hi; b0 += 64 * SO_SCAN) {              // SO_SCAN loads in flight: the list comes from L2, ~0.3 us a trip
-    int rr[SO_SCAN];
-#pragma unroll
-    for (int q = 0; q < SO_SCAN; ++q) {
-      const long i = b0 + 64 * q + lane;
-      rr[q] = i < hi ? rows[i] : -1;
-    }
-#pragma unroll
-    for (int q = 0; q < SO_SCAN; ++q) {
-      const long i = b0 + 64 * q + lane;
-      const int r = rr[q];
-      const bool mine = i < hi && (r & gmask) == me;
-      const unsigned long long m = __ballot(mine);
-      if (mine) {
-        const int pos = cnt + __popcll(m & lt);
-        if (pos < SO_CAPW) {
-          w_row[wave][pos] = r;
-          w_src[wave][pos] = in_idx ? in_idx[i] : (int)i;
-        }
-      }
-      cnt += __popcll(m);
-    }
-  }
-  if (lane == 0) w_cnt[wave] = cnt;
-  __syncthreads();
-  int off = 0, E = 0;
-  bool over = false;
-#pragma unroll
-  for (int w = 0; w < SO_WAVES; ++w) {
-    const int c = w_cnt[w];
-    const int k = c < SO_CAPW ? c : SO_CAPW;
-    if (w < wave) off += k;
-    E += k;
-    over |= c > SO_CAPW;
-  }
-  for (int k = lane; k < (cnt < SO_CAPW ? cnt : SO_CAPW); k += 64) {
-    l_row[off + k] = w_row[wave][k];
-    l_src[off + k] = w_src[wave][k];
-  }
-  __syncthreads();
-
-  // ---- owner pass
-  for (int g0 = wave; g0 < E; g0 += SO_BATCH * SO_WAVES) {
-    int row[SO_BATCH], src[SO_BATCH];
-    float2 x[SO_BATCH], tv[SO_BATCH];
-#pragma unroll
-    for (int u = 0; u < SO_BATCH; ++u) {
-      const int g = g0 + SO_WAVES * u < E ? g0 + SO_WAVES * u : E - 1;
-      row[u] = l_row[g];
-      src[u] = l_src[g];
-    }
-#pragma unroll
-    for (int u = 0; u < SO_BATCH; ++u) {
-      x[u] = *reinterpret_cast<const float2*>(dOut + (long)src[u] * ldo + 2 * lane);
-      tv[u] = *reinterpret_cast<const float2*>(dW + (long)row[u] * ldw + 2 * lane);
-    }
-#pragma unroll
-    for (int u = 0; u < SO_BATCH; ++u) {
-      const int g = g0 + SO_WAVES * u;
-      if (g >= E) break;                                       // wave-uniform
-      bool dup = false;
-      for (int b = 0; b < g && !dup; b += 64) dup = __ballot(b + lane < g && l_row[b + lane] == row[u]) != 0;
-      if (dup) continue;
-      float2 acc = make_float2(tv[u].x + x[u].x, tv[u].y + x[u].y);
-      for (int b = g + 1; b < E; b += 64) {
-        unsigned long long m = __ballot(b + lane < E && l_row[b + lane] == row[u]);
-        while (m) {
-          const int bit = __builtin_ctzll(m);
-          m &= m - 1;
-          const float2 y = *reinterpret_cast<const float2*>(dOut + (long)l_src[b + bit] * ldo + 2 * lane);
-          acc.x += y.x;
-          acc.y += y.y;
-        }
-      }
-      *reinterpret_cast<float2*>(dW + (long)row[u] * ldw + 2 * lane) = acc;
-    }
-  }
-  if (!over) return;                                           // workgroup-uniform
-
-  // ---- entries past a wave's capacity: float atomics, after the owner's plain stores
-  __threadfence();
-  __syncthreads();
-  if (cnt <= SO_CAPW) return;
-  int seen = 0;
-  for (long b = lo; b < hi; b += 64) {
-    const long i = b + lane;
-    const int r = i < hi ? rows[i] : -1;
-    const bool mine = i < hi && (r & gmask) == me;
-    unsigned long long m = __ballot(mine);
-    const int before = seen;
-    seen += __popcll(m);
-    if (seen <= SO_CAPW) continue;
-    int k = 0;
-    while (m) {
-      const int bit = __builtin_ctzll(m);
-      m &= m - 1;
-      if (before + k++ < SO_CAPW) continue;
-      const long j = b + bit;
-      const long s = in_idx ? in_idx[j] : j;
-      const long d = rows[j];
-      atomicAdd(&dW[d * ldw + lane], dOut[s * ldo + lane]);
-      atomicAdd(&dW[d * ldw + 64 + lane], dOut[s * ldo + 64 + lane]);
-    }
-  }
-}
-
 extern "C" int sbr_scatter_add_rows(const float* dOut, long ldo, const int* in_idx, const int* rows, float* dW,
                                     long ldw, long n, int D, void* stream) {
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(dOut && rows && dW, "sbr_scatter_add_rows: null operand");
-  if (D == 128 && n >= 4096 && n <= 131072 && ldo % 2 == 0 && ldw % 2 == 0 && ((uintptr_t)dOut | (uintptr_t)dW) % 8 == 0 &&
-      getenv("SBR_SCATTER_OWNED") && atoi(getenv("SBR_SCATTER_OWNED")) == 1) {
-    // OPT-IN experiment (correct, deterministic, measured slower): on uniformly drawn rows 25.8 us against the atomic kernel's
-    // 23.5 us (45,824 x 128; 37 against 29 us with a cold table), and on the training step's own lists 227 us on average: a
-    // graph-mode step pads every modality's slot list with ~770 sentinel slots that all name ONE table row (zero gradient rows,
-    // engine._EntityRun.plan), i.e. one workgroup owns a chain of hundreds of entries and most of them overflow into its atomic
-    // tail. The atomic kernel stays the product path.
-    scatter_add_rows_owned_kernel<<<256, 64 * SO_WAVES, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n);
-    SBR_CHECK_LAUNCH("sbr_scatter_add_rows");
-    return SBR_OK;
-  }
-  if (D == 128 && n >= 4096 && !(getenv("SBR_SCATTER_V1") && atoi(getenv("SBR_SCATTER_V1")) != 0)) {
+  if (D == 128 && n >= 4096) {
     int blocks = (int)sbr_cdiv(n, 16);                           // >= 4 rows per wave
     if (blocks > 2048) blocks = 2048;                            // 8 workgroups of 4 waves per CU
     scatter_add_rows128_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dOut, ldo, in_idx, rows, dW, ldw, n);

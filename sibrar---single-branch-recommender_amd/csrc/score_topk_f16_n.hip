@@ -683,7 +683,7 @@ static long s5_event_bytes(long Bu, long excl_nnz) {
   return s5_al16((G + 1) * 4) + s5_al16(G * 4) + s5_al16(Bu * 4) + s5_al16(Bu * 8) + s5_al16((excl_nnz + 11 * G) * 4) + 16;
 }
 
-long s5_workspace_bytes(long Bu, long excl_nnz) {
+static long s5_workspace_bytes(long Bu, long excl_nnz) {
   // users padded to whole workgroups of any wave count (< 32 * S5_MAXW extra) + the cycle stamps of SBR_ST_DEBUG + the events
   const long padded = Bu + 32L * S5_MAXW;
   return padded * 2 * S5_CAPH * 8 + (sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L + s5_event_bytes(Bu, excl_nnz);
@@ -757,8 +757,8 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
   return SBR_OK;
 }
 
-// D in {64, 128, 256}; called by sbr_score_topk_f16 (score_topk_f16.hip)
-int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
+// D in {64, 128, 256}
+static int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
                 int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
   switch (D) {
     case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
@@ -768,4 +768,38 @@ int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long
       sbr_set_error("sbr_score_topk_f16: D=%d not supported by the narrow-wave kernel", D);
       return SBR_ERR_ARG;
   }
+}
+
+// bytes of the workspace of one call: candidate buffers (users padded to whole workgroups), cycle stamps of SBR_ST_DEBUG, and the
+// exclusion-event region
+extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k, long excl_nnz) {
+  (void)I; (void)k;
+  return s5_workspace_bytes(Bu, excl_nnz);
+}
+
+extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
+                                  const long* excl_indptr, const int* excl_indices, long excl_nnz, int item_offset, int k, float* out_val,
+                                  int* out_idx, void* workspace, long workspace_bytes, void* stream) {
+  SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
+  SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
+  if (Bu == 0) return SBR_OK;
+  SBR_REQUIRE(U_f16 && I_f16 && out_val && out_idx, "sbr_score_topk_f16: null operand");
+  SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
+  SBR_REQUIRE(D == 64 || D == 128 || D == 256, "sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
+  return s5_dispatch(U_f16, I_f16, D, Bu, I, u_idx, excl_indptr, excl_indices, excl_nnz, item_offset, k, out_val, out_idx, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+__global__ void cast_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Y, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) Y[e] = (_Float16)X[e];
+}
+
+extern "C" int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream) {
+  if (n == 0) return SBR_OK;
+  SBR_REQUIRE(X && Y_f16, "sbr_cast_f32_to_f16: null operand");
+  int blocks = sbr_cdiv(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  cast_f16_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, (_Float16*)Y_f16, n);
+  SBR_CHECK_LAUNCH("sbr_cast_f32_to_f16");
+  return SBR_OK;
 }

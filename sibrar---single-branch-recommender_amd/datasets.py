@@ -246,8 +246,7 @@ class NegativeSamplingDataLoader:
 
         out = queue.Queue(maxsize=self.prefetch)
         threads = []
-        two_stage = self.batch_size * (1 + self.n_neg) >= 32768 if os.environ.get('SBR_LOADER_STAGES') is None \
-            else os.environ['SBR_LOADER_STAGES'] == '2'
+        two_stage = self.batch_size * (1 + self.n_neg) >= 32768
         if self.prepare_fn is None or not two_stage:
             # small batches: every numpy call is too short to release the GIL, a second producer thread only adds hand-offs
             threads.append(threading.Thread(target=stage, args=(self._produce(), out, lambda b: b), daemon=True))

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from ._lib import call, pin_stream, ptr, to_device, use_stream
+from ._lib import call, pin_stream, ptr, to_device
 from .config import EmbeddingRegularizationType
 from .losses import RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy, RecSampledSoftmaxLoss
 from .sbnet import FeatureEmbedding, SingleBranchNet, SingleBranchNetEntity, resolve_rows
@@ -99,16 +99,8 @@ class _EntityRun:
         # whenever a step draws one modality per slot; the normalised representation is then never stored
         self.fuse_tail = False
         self.tail = None             # (z, mean, rstd) of the current step when the tail is fused
-        self.fold = os.environ.get('SBR_FOLD_COLSUM', '1') != '0'
-        # OPT-IN experiment (SBR_BRANCH_LOOKUPS=1), measured SLOWER: lookup-type modalities (embedding / tag bag: HBM gathers and
-        # float-atomic scatters, no allocation, rows disjoint from the other modalities') as a parallel branch next to the dense
-        # projectors' GEMMs — a second stream, i.e. a second branch of the captured graph — so that the 43 us item-table scatter and
-        # the 12 us lookup of c2 would hide behind 99 / 96 us of MFMA work. Results are identical (all tests pass), but a replayed
-        # hipGraph with two fork / join pairs takes 1.50 ms per step instead of 0.78 (B = 256: 1.3 instead of 0.31 ms) on ROCm
-        # 7.2: cross-branch edges of a graph are far more expensive than the work they would overlap. Linear graphs only.
-        self.branch = os.environ.get('SBR_BRANCH_LOOKUPS', '0') == '1'
-        self._side = None
-        self.tn = ops.DeferredTN() if os.environ.get('SBR_DEFER_SPLITK', '1') != '0' else None   # dW slabs summed by one launch
+        self.fold = True             # bias-gradient column sums ride on the kernels that produce their input
+        self.tn = ops.DeferredTN()                       # dW slabs summed by one launch
         self._dx0 = {}               # (R, C) -> persistent [R + 1, C] slot-gradient buffer with a zero sentinel row (graph mode)
 
     # ---- forward -----------------------------------------------------------------------------------------------------
@@ -173,22 +165,7 @@ class _EntityRun:
         rows, _ = resolve_rows(idx_flat, k, slots, offs, tables, ent._idx_err)
         self.entries, self.rows, self.slots, self.R, self.k, self.shape = entries, rows, slots, R, k, tuple(idx.shape)
         x0 = a.f32(R + 1 if padded else R, self.C)      # row R: landing row of the padded launches
-        light = [fe.kind in ('categorical', 'tag') for fe, _, _ in entries]
-        fork = self.branch and any(light) and not all(light)
-        self.hidden = [None] * len(entries)
-        if fork:
-            if self._side is None:
-                self._side = torch.cuda.Stream(x0.device)
-            with use_stream(self._side) as br:
-                for q, (fe, o, n) in enumerate(entries):
-                    if light[q]:
-                        self.hidden[q] = fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n])
-        for q, (fe, o, n) in enumerate(entries):
-            if not (fork and light[q]):
-                self.hidden[q] = fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n])
-        if fork:
-            br.join()
-        self._forked = fork
+        self.hidden = [fe.front_forward(fe.front_params(), rows[o:o + n], n, x0, slots[o:o + n]) for fe, o, n in entries]
         self.x0 = x0
         x = x0[:R]
         if self.normalize:
@@ -378,10 +355,7 @@ class _EntityRun:
                 bias_done = True
             else:
                 dz = ops.act_grad(d, y, act) if act else d
-            if self.tn is not None:
-                self.tn.matmul_tn(id(lin), dz, x, out=_grad_of(w))
-            else:
-                ops.matmul_tn(dz, x, out=_grad_of(w))
+            self.tn.matmul_tn(id(lin), dz, x, out=_grad_of(w))
             if not bias_done:
                 ops.colsum(dz, out=_grad_of(lin.bias))
             last = li == len(self.layers) - 1
@@ -412,27 +386,13 @@ class _EntityRun:
         if d.data_ptr() != dx0.data_ptr():               # no layer at all: the incoming gradient is the matrix gradient
             torch.mul(d, 1.0, out=dx0[:R])                # a kernel node, not a memcpy node (see DESIGN.md §5 on memset nodes)
         d = dx0
-        br = None
-        if self._forked:
-            with use_stream(self._side) as br:
-                for (fe, o, n), hs in zip(self.entries, self.hidden):
-                    if fe.kind in ('categorical', 'tag'):
-                        ps = fe.front_params()
-                        fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n],
-                                          grad_out=[_grad_of(p) for p in ps])
         for (fe, o, n), hs in zip(self.entries, self.hidden):
-            if br is not None and fe.kind in ('categorical', 'tag'):
-                continue
             ps = fe.front_params()
             fe.front_backward(ps, hs, self.rows[o:o + n], n, self.x0, d, self.slots[o:o + n], grad_out=[_grad_of(p) for p in ps],
                               pending=pending, tn=self.tn)
-        took = False
-        if self.tn is not None:
-            took = self.tn.finish(pending)             # ... and the pending bias-gradient column sums, in the same launch
+        took = self.tn.finish(pending)                 # ... and the pending bias-gradient column sums, in the same launch
         if pending and not took:
             ops.colred_finish(pending)
-        if br is not None:
-            br.join()
 
 
 _IDENTITY_SLOTS = {}
@@ -666,7 +626,7 @@ class FusedTrainStep:
         shift = math.log(rl.n_items / rl.neg_train) if (self.kind == 2 and rl.train_neg_strategy == 'uniform') else 0.0
         no_reg = self.user.reg_loss is None and self.item.reg_loss is None
         self._packed = None
-        if (tail is not None and no_reg and B >= 1 and os.environ.get('SBR_FUSED_LOSS', '1') != '0'
+        if (tail is not None and no_reg and B >= 1
                 and ops.lib().sbr_bn_score_loss_supported(int(D), int(N))):
             # scorer forward, loss + dlogits and the first backward pass of the fused tail in ONE launch: the slot rows of a user
             # stay in registers between the logits and the backward statistics (csrc/fused_tail.hip: bn_score_loss_kernel)
@@ -697,14 +657,20 @@ class FusedTrainStep:
         loss = a.f64()
         dlog = a.f32(B, N)
         self._packed = None
-        if no_reg and B >= 1 and os.environ.get('SBR_LOSS_WS', '1') != '0':
+        if no_reg and B >= 1:
             # one launch: no zeroing launch in front, block partial sums added in a fixed order, and the packed (total, rec, reg)
             # scalars of the step written by the same kernel (no regularisation losses: total = rec)
             need = int(ops.lib().sbr_rec_loss_workspace(B))
             if self._loss_ws is None or self._loss_ws.numel() * 8 < need:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError('the loss workspace must exist before a step is captured (run one plain step first)')
-                self._loss_ws = torch.zeros((need + 7) // 8, device=logits.device, dtype=torch.float64)
+                if self._loss_ws is not None:
+                    # outgrown by a larger batch: steps captured earlier have the old address baked in (counter + partials), so the
+                    # old block is retired — never handed back to the caching allocator — and those graphs are dropped
+                    ops._WS_RETIRED.append(self._loss_ws)
+                    self._graphs.clear()
+                self._loss_ws = torch.zeros((max(need, int(ops.lib().sbr_rec_loss_workspace(1 << 16))) + 7) // 8, device=logits.device,
+                                            dtype=torch.float64)
             self._packed = a.f64(3)
             call('sbr_rec_loss_fwd_bwd_ws', self.kind, ptr(logits), ptr(lab), B, N, scale, shift, ptr(loss), ptr(dlog),
                  ptr(self._packed), ptr(self._loss_ws), self._loss_ws.numel() * 8, st)
@@ -921,8 +887,6 @@ class FusedTrainStep:
                 # step() + zero_grad() in the optimizer's own launch — which also carries the step's loss scalars out of the
                 # captured step's static buffer into a fresh tensor (instead of a clone launch)
                 static = out if torch.is_tensor(out) else None
-                if static is not None and os.environ.get('SBR_LOSS_COPY', '1') == '0':      # A/B: clone launch instead
-                    out, static = static.clone().unbind(0), None
                 fresh = torch.empty_like(static) if static is not None else None
                 took = self.opt.step_flat(zero_grad=True, copy=(static, fresh) if static is not None else None)
                 if static is not None:

@@ -139,7 +139,11 @@ class FullEvaluator:
         m = torch.cat([ops.rank_metrics(topk_idx, u_long, indptr, indices, ks[c:c + RANK_METRIC_MAX_KS])
                        for c in range(0, len(ks), RANK_METRIC_MAX_KS)], dim=1) if ks else None
         for name in (self._user_features or ()):
-            self._groups[name].append(self._group_map(name, topk_idx.device)[0][u_long])
+            gmap = self._group_map(name, topk_idx.device)[0]
+            # ids beyond the map (only possible when the dataset does not state n_users): category -1 -> KeyError in get_results
+            self._groups[name].append(torch.where(u_long < gmap.numel(), gmap[u_long.clamp(max=max(gmap.numel() - 1, 0))],
+                                                  torch.full_like(u_long, -1, dtype=torch.int32)) if gmap.numel() else
+                                      torch.full_like(u_long, -1, dtype=torch.int32))
         for qi, k in enumerate(ks):
             nd, rc, pr = m[0, qi], m[1, qi], m[2, qi]
             if 'ndcg' in self.config.metrics:
@@ -164,7 +168,10 @@ class FullEvaluator:
             f = self.dataset.user_features[name]
             vals = np.asarray(f.values).astype(np.int64).reshape(-1)
             ids = np.asarray(getattr(f, '_indices', np.arange(len(vals)))).astype(np.int64)
-            cat = np.full(int(ids.max()) + 1 if len(ids) else 0, -1, dtype=np.int32)
+            # one entry per user id the evaluation can name (ids without a value of this feature stay -1 and raise KeyError in
+            # get_results, as eval/eval.py:110-113 does on the host) — never a device gather past the end of the map
+            n_ids = max(int(ids.max()) + 1 if len(ids) else 0, int(getattr(self.dataset, 'n_users', 0) or 0))
+            cat = np.full(n_ids, -1, dtype=np.int32)
             cat[ids] = vals
             uniq = getattr(f, 'unique_values', None)
             n_cat = int(vals.max()) + 1 if len(vals) else 0

@@ -77,7 +77,6 @@ def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, 
 
 import os as _os
 
-_WRES = _os.environ.get('SBR_GEMM_WRES', '1') != '0'
 # fp32 products on the bf16 matrix pipe over exact three-way operand splits (csrc/gemm_split_f32.hip); '0' keeps every product on
 # the fp32 pipe (v_mfma_f32_32x32x2_f32)
 _SPLIT = _os.environ.get('SBR_GEMM_SPLIT', '1') != '0'
@@ -94,7 +93,7 @@ def _mlp_kernel(M, N, K) -> str:
 def _wres_ok(M, N, K, *tensors) -> bool:
     """The weights-resident kernel (csrc/gemm_wres_f32.hip) takes the shared MLP's own products: N = K = 128, no gathers,
     16-byte aligned rows."""
-    if not _WRES or M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
+    if M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
         return False
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
 
@@ -233,19 +232,12 @@ def matmul_tn(dz, x, a_idx=None, b_idx=None, n_rows=None, out=None):
 class DeferredTN:
     """dW products of one backward pass whose split-K slabs are summed by ONE launch at the end (sbr_splitk_reduce_multi).
     Every product keeps its own persistent slab workspace under a caller-chosen key: captured step graphs hold the addresses, so an
-    outgrown workspace is retired (kept allocated), never freed.
-    ``group`` (default OFF, ``SBR_TN_GROUP=1`` on): the slab launches themselves wait for ``finish()`` too and go out as ONE grouped
-    launch (``sbr_gemm_tn_f32_slabs_multi``) — the operands must then stay untouched until ``finish()`` (they do in the fused step:
-    arena tensors of the running step). Measured on the c2 step: 0.564 ms per step against 0.559 with one launch per product — the
-    two launch floors it saves are outweighed (the gradient rows a product reads have left the caches by the end of the backward
-    pass, and 12-chunk and 36-chunk workgroups share one grid) — so it stays an option. While ``KernelTimer`` brackets launches
-    every product is launched on its own."""
+    outgrown workspace is retired (kept allocated), never freed. (Measured and dropped: the slab launches themselves as one grouped
+    launch at ``finish()`` — 5 us slower per c2 step than one launch per product)"""
 
-    def __init__(self, group=None):
+    def __init__(self):
         self.ws = {}                 # key -> float32 workspace tensor
         self.pending = []            # (workspace, out, M, N, splits)
-        self.queued = []             # products whose slab launch waits for finish(): (ws, out, M, N, R, dz, x, a_idx, b_idx)
-        self.group = (_os.environ.get('SBR_TN_GROUP', '0') == '1') if group is None else bool(group)
 
     def matmul_tn(self, key, dz, x, a_idx=None, b_idx=None, n_rows=None, out=None):
         import ctypes
@@ -260,9 +252,6 @@ class DeferredTN:
                 _WS_RETIRED.append(ws)
             ws = self.ws[key] = torch.empty(max((need + 3) // 4, 2 * ws.numel() if ws is not None else 0), device=dz.device,
                                             dtype=torch.float32)
-        if self.group and not KernelTimer.enabled:
-            self.queued.append((ws, out, M, N, R, dz, x, a_idx, b_idx))
-            return out
         splits = ctypes.c_int(0)
         _timed(('gemm_f32', 2, M, N, R, a_idx is not None or b_idx is not None),
                lambda: call('sbr_gemm_tn_f32_slabs', ptr(dz), dz.stride(0), ptr(a_idx), ptr(x), x.stride(0), ptr(b_idx), M, N, R,
@@ -270,35 +259,11 @@ class DeferredTN:
         self.pending.append((ws, out, M, N, splits.value))
         return out
 
-    def _launch_queued(self):
-        import ctypes
-        # longest workgroups first (work per workgroup ~ K * tiles): the hardware hands workgroups out in index order, and a product
-        # whose workgroups run three times as long must not start last
-        order = sorted(self.queued, key=lambda p: -(p[4] * (p[2] // 128) * (p[3] // 128))) if len(self.queued) <= 4 else self.queued
-        for lo in range(0, len(order), 4):
-            part = order[lo:lo + 4]
-            n = len(part)
-            arr = lambda ct, vals: ctypes.cast((ct * n)(*vals), ctypes.c_void_p)
-            pv = lambda t: 0 if t is None else t.data_ptr()
-            splits = (ctypes.c_int * n)()
-            call('sbr_gemm_tn_f32_slabs_multi', n, arr(ctypes.c_void_p, [p[5].data_ptr() for p in part]),
-                 arr(ctypes.c_long, [p[5].stride(0) for p in part]), arr(ctypes.c_void_p, [pv(p[7]) for p in part]),
-                 arr(ctypes.c_void_p, [p[6].data_ptr() for p in part]), arr(ctypes.c_long, [p[6].stride(0) for p in part]),
-                 arr(ctypes.c_void_p, [pv(p[8]) for p in part]), arr(ctypes.c_int, [p[2] for p in part]),
-                 arr(ctypes.c_int, [p[3] for p in part]), arr(ctypes.c_int, [p[4] for p in part]),
-                 arr(ctypes.c_void_p, [p[0].data_ptr() for p in part]), arr(ctypes.c_long, [p[0].numel() * 4 for p in part]),
-                 ctypes.cast(splits, ctypes.c_void_p), stream())
-            for p, sp in zip(part, splits):
-                self.pending.append((p[0], p[1], p[2], p[3], int(sp)))
-        self.queued = []
-
     def finish(self, colred=None):
         """Sums the slabs of the pending products. ``colred`` (optional): [(workspace, out float vector [C])] of folded column sums
         — at most 8, with at most 8 pending products — finished by the same launch (``sbr_splitk_reduce_multi_fin``) instead of a
         ``colred_finish`` launch of their own; returns True when they were taken."""
         import ctypes
-        if self.queued:
-            self._launch_queued()
         took = False
         fuse = colred and 0 < len(colred) <= 8 and 0 < len(self.pending) <= 8
         for lo in range(0, len(self.pending), 8):

@@ -155,7 +155,7 @@ def recbole_negative_collate(user_idx: np.ndarray, pos_item_idx: np.ndarray, n_n
     h_indptr = getattr(positives, '_h_indptr', None)
     # a slot's user is user_idx[slot % B]: the B rows of the CSR that a batch touches become cache-resident after the first round,
     # whatever the size of the CSR, so the host search is cheap for small batches even on large interaction matrices
-    if (h_indptr is not None and 0 < total <= int(os.environ.get('SBR_NATIVE_COLLATE_MAX', '8192')) and np.ndim(pos_item_idx) == 1
+    if (h_indptr is not None and 0 < total <= 8192 and np.ndim(pos_item_idx) == 1
             and 1 <= n_cand <= 0xFFFFFFFF and os.environ.get('SBR_NATIVE_COLLATE', '1') != '0'):
         return _recbole_collate_native(user_idx, pos_item_idx, n_neg, items_in_split, identity, positives)
 

@@ -657,47 +657,6 @@ def test_scatter_add_rows_sorted_is_the_dense_gradient_without_atomics(W, cap, D
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize('n,n_table,skew,gather', [(4096, 5000, 0, False), (45824, 50000, 0, True), (8192, 100000, 0, False),
-                                                  (20000, 3000, 1, True), (9000, 40, 2, True), (131072, 70000, 1, False)])
-def test_scatter_add_rows_owner_kernel_is_the_dense_gradient_without_atomics(n, n_table, skew, gather, monkeypatch):
-    """The opt-in atomic-free form of sbr_scatter_add_rows (SBR_SCATTER_OWNED=1; D = 128 and 4,096 - 131,072 rows; csrc/rowops.hip
-    scatter_add_rows_owned_kernel; measured slower than the atomic kernel, kept as a recorded experiment): every workgroup
-    owns the table rows r mod 256 = its index, adds the gradient rows of a table row in slot order with plain stores — equal to
-    index_add in float64, the same bits on a second run, equal to the product's atomic kernel (SBR_SCATTER_OWNED=0) up to rounding; uniform
-    rows, popularity-skewed rows (one row drawn thousands of times: the per-wave list capacity overflows into the atomic tail),
-    a tiny table (every entry of a wave's scan is owned by few workgroups), an indexed source (in_idx) and a plain one."""
-    from importlib import import_module
-    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
-    D = 128
-    g = torch.Generator().manual_seed(n + skew)
-    n_src = n + 100
-    grads = torch.randn(n_src, D, generator=g)
-    if skew == 0:
-        rows = torch.randint(0, n_table, (n,), generator=g, dtype=torch.int32)
-    elif skew == 1:
-        rows = (torch.rand(n, generator=g) ** 6 * n_table).to(torch.int32).clamp_(max=n_table - 1)      # row 0 thousands of times
-    else:
-        rows = torch.randint(0, n_table, (n,), generator=g, dtype=torch.int32)
-    in_idx = torch.randperm(n_src, generator=g)[:n].to(torch.int32) if gather else None
-    src = grads[in_idx.long()] if gather else grads[:n]
-    ref = torch.full((n_table, D), 0.25, dtype=torch.float64)
-    ref.index_add_(0, rows.long(), src.double())
-    mag = torch.full((n_table, D), 0.25, dtype=torch.float64)
-    mag.index_add_(0, rows.long(), src.double().abs())
-    gd, rd = grads.to(DEV), rows.to(DEV)
-    idd = in_idx.to(DEV) if gather else None
-    outs = {}
-    for flag in ('1', '1', '0'):
-        monkeypatch.setenv('SBR_SCATTER_OWNED', flag)
-        dW = torch.full((n_table, D), 0.25, device=DEV)
-        _lib.call('sbr_scatter_add_rows', gd.data_ptr(), D, _lib.ptr(idd), rd.data_ptr(), dW.data_ptr(), D, n, D, _lib.stream())
-        outs.setdefault(flag, []).append(dW.double().cpu())
-    for o in outs['1'] + outs['0']:
-        assert bool(((o - ref).abs() <= 2.0 ** -20 * mag).all())
-    if skew != 1:                                              # no atomic tail: a fixed summation order
-        assert torch.equal(outs['1'][0], outs['1'][1])
-
-
 @pytest.mark.parametrize('name', ['adamw', 'adam'])
 def test_deferred_row_wise_adam_replay_is_bit_identical(name):
     """sbr_adam_rows (engine.DeferredTable): a lookup table whose rows take the optimizer steps they missed later, in order, with
@@ -901,38 +860,6 @@ def test_split_projector_gemm_has_the_error_of_the_fp32_pipe(M, K, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,K,gather', [(128, 9001, False), (768, 8200, True), (256, 20011, True)])
-def test_direct_tn_kernel_matches_fp64_and_the_ring_kernel(N, K, gather, monkeypatch):
-    """sbr_gemm_tn_f32 on the weight-gradient shapes (M = 128, N = 128 j, long K) takes the LDS-free direct kernel
-    (csrc/gemm_tn_direct_f32.hip): against an fp64 product and next to the ring kernel (SBR_TN_DIRECT=0) on the same call — plain
-    and row-gathered operands, K ranges that end inside a 16-row step, the deferred-slab path summed by sbr_splitk_reduce_multi."""
-    ops = S().ops
-    g = torch.Generator().manual_seed(9)
-    n_src = 5000
-    dz = _rand(K, 128, seed=61).to(DEV)
-    x = _rand(n_src if gather else K, N, seed=62).to(DEV)
-    b_idx = torch.randint(0, n_src, (K,), generator=g, dtype=torch.int32).to(DEV) if gather else None
-    xd = x.double().cpu()[b_idx.cpu().long()] if gather else x.double().cpu()
-    want = dz.double().cpu().t() @ xd
-    mag = dz.double().cpu().abs().t() @ xd.abs()
-    got = {}
-    monkeypatch.setenv('SBR_TN_SPLIT', '0')                   # the bf16-split kernel would take these shapes first
-    for flag in ('1', '0'):
-        monkeypatch.setenv('SBR_TN_DIRECT', flag)
-        got[flag] = ops.matmul_tn(dz, x, b_idx=b_idx, n_rows=K).double().cpu()
-    e_direct = ((got['1'] - want).abs() / mag).max().item()
-    e_ring = ((got['0'] - want).abs() / mag).max().item()
-    assert e_direct <= max(2.0 * e_ring, 2.0 ** -20), (e_direct, e_ring)
-    # deferred slabs + the shared reducer give the same bits as the immediate reduction (same slabs, same summation order)
-    monkeypatch.setenv('SBR_TN_DIRECT', '1')
-    d = ops.DeferredTN()
-    out = torch.empty(128, N, device=DEV)
-    d.matmul_tn('t', dz, x, b_idx=b_idx, n_rows=K, out=out)
-    d.finish()
-    assert torch.equal(out.double().cpu(), got['1'])
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize('M,N,K,gather', [(128, 128, 4096, ''), (128, 128, 9001, ''), (128, 128, 90112, 'a'), (128, 768, 8200, 'b'),
                                           (128, 256, 20011, 'ab'), (128, 768, 45824, 'b'), (128, 128, 600000, ''), (256, 128, 9001, 'b'),
                                           (512, 512, 30011, 'a')])
@@ -969,39 +896,6 @@ def test_split_tn_kernel_has_the_error_of_the_fp32_pipe(M, N, K, gather, monkeyp
     d.matmul_tn('t', dz, x, a_idx=a_idx, b_idx=b_idx, n_rows=K, out=out)
     d.finish()
     assert torch.equal(out.double().cpu(), got['1'])
-
-
-@pytest.mark.gpu
-def test_deferred_dw_products_go_out_as_one_grouped_launch():
-    """DeferredTN(group=True): the slab launches of the queued products wait for finish() and leave as ONE grouped launch of the
-    bf16-split kernel (sbr_gemm_tn_f32_slabs_multi) — the bits of one launch per product (group=False): the c2 step's three dW
-    shapes (128 x 128 twice, 128 x 768 row-gathered), a mixed call in which one product is not eligible (K < 4096: every product
-    then takes its own launch), and five products (two grouped launches)."""
-    ops = S().ops
-    g = torch.Generator().manual_seed(3)
-    dz1, h1 = _rand(90112, 128, seed=11).to(DEV), _rand(90112, 128, seed=12).to(DEV)
-    dz2, x0 = _rand(90112, 128, seed=13).to(DEV), _rand(90112, 128, seed=14).to(DEV)
-    dzp, X = _rand(45824, 128, seed=15).to(DEV), _rand(5000, 768, seed=16).to(DEV)
-    rows = torch.randint(0, 5000, (45824,), generator=g, dtype=torch.int32).to(DEV)
-    small_a, small_b = _rand(3000, 128, seed=17).to(DEV), _rand(3000, 128, seed=18).to(DEV)
-    cases = {'c2': [(dz1, h1, None, None), (dz2, x0, None, None), (dzp, X, rows, 45824)],
-             'mixed': [(dz1, h1, None, None), (small_a, small_b, None, None), (dzp, X, rows, 45824)],
-             'five': [(dz1, h1, None, None), (dz2, x0, None, None), (dzp, X, rows, 45824), (dz2, h1, None, None), (dz1, x0, None, None)]}
-    for name, prods in cases.items():
-        res = {}
-        for group in (True, False):
-            d = ops.DeferredTN(group=group)
-            outs = []
-            for q, (a, b, bi, n) in enumerate(prods):
-                o = torch.empty(128, b.shape[1], device=DEV)
-                d.matmul_tn(('k', q), a, b, b_idx=bi, n_rows=n, out=o)
-                outs.append(o)
-            assert len(d.queued) == (len(prods) if group else 0)
-            d.finish()
-            assert not d.queued and not d.pending
-            res[group] = [o.clone() for o in outs]
-        for a, b in zip(res[True], res[False]):
-            assert torch.equal(a, b), name
 
 
 @pytest.mark.gpu

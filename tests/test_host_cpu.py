@@ -180,7 +180,8 @@ import os, sys
 sys.path.insert(0, {root!r})
 import numpy as np, torch, torch.distributed as dist
 import sibrar_amd as S
-dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+dist.init_process_group('gloo', init_method='file://' + os.environ['SBR_RDZV_FILE'], rank=int(os.environ['RANK']),
+                        world_size=int(os.environ['WORLD_SIZE']))
 rank, world = dist.get_rank(), dist.get_world_size()
 # (1) flat gradient all-reduce == mean of the per-rank gradients
 g = torch.arange(10, dtype=torch.float32) * (rank + 1)
@@ -211,24 +212,13 @@ print('rank', rank, 'ok')
 
 
 def test_two_rank_gloo_data_parallel_and_item_sharding(tmp_path):
+    """Rendezvous through a FileStore (no port to pick, nothing to retry: a failure of the ranks is a failure of the test)."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(root=ROOT))
-    import socket
-    for attempt in range(3):
-        with socket.socket() as sock:                 # a free port (a fixed one collides with lingering sockets of earlier runs)
-            sock.bind(('127.0.0.1', 0))
-            port = sock.getsockname()[1]
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
-        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
-        outs = [p.communicate(timeout=300)[0] for p in procs]
-        # the port is free when it is picked and may be taken by the time the store binds it, and the gloo rendezvous itself can time
-        # out on a loaded host: retry the RENDEZVOUS (never an assertion of the worker, whose output carries 'AssertionError')
-        infra = any(p.returncode != 0 and 'AssertionError' not in o and
-                    any(k in o for k in ('Address already in use', 'EADDRINUSE', 'Connection', 'connect', 'timed out', 'Timeout', 'store'))
-                    for p, o in zip(procs, outs))
-        if not infra:
-            break
+    env = dict(os.environ, SBR_RDZV_FILE=str(tmp_path / 'rdzv'), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f'rank {r} failed:\n{o}'
         assert f'rank {r} ok' in o
