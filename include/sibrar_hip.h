@@ -60,6 +60,8 @@ int sbr_gemm_nt_splitk_f32(const float* A, long lda, const int* a_idx, const flo
 /* TN with a deterministic split-K slab reducer (no atomics): C[m, n] = sum_k A[ak(k), m] * B[bk(k), n], C overwritten.
  * autograd of nn.Linear w.r.t. its weight (dW = dZ^T X[rows]). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes. */
 long sbr_gemm_tn_f32_workspace(int M, int N, int K);
+/* 1 when sbr_gemm_tn_f32 / _slabs serve this shape with the bf16-split kernel (csrc/gemm_split_tn_f32.hip), 0: fp32 ring kernel */
+int sbr_gemm_tn_split_supported(int M, int N, int K);
 int sbr_gemm_tn_f32(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, float* C, long ldc,
                     int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
 /* The same product with the reduction deferred: sbr_gemm_tn_f32_slabs writes only the partial slabs (the workspace then belongs to
@@ -363,6 +365,9 @@ int sbr_adagrad_step(float* p, const float* g, float* state_sum, long n, double 
  * exclusion mask out[b, excl(u_b)] = -inf (eval/eval.py:219-220) from the CSR `exclude_data` (data/dataset.py:416-438) */
 int sbr_mask_scores(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices, long Bu,
                     void* stream);
+/* the same when `scores` holds the item columns [item_offset, item_offset + n_cols) only (new: item-sharded evaluation) */
+int sbr_mask_scores_shard(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices, long Bu,
+                          int item_offset, int n_cols, void* stream);
 /* exact per-row top-k, sorted by (score desc, index asc) — torch.topk at eval/eval.py:320 and inside rmet.calculate */
 int sbr_topk_rows(const float* scores, long ld, long Bu, int I, int k, float* out_val, int* out_idx, void* stream);
 /* exact merge of W per-shard top-k lists of an item-sharded evaluation (new: the reference has no multi-GPU path):

@@ -79,6 +79,7 @@ _FN = {}
 
 
 _TRACE = os.environ.get('SBR_TRACE_CALLS', '0') == '1'
+CALL_LOG = None      # tests: set to a list and every entry point called through ``call`` is appended as (name, args)
 
 
 def call(name: str, *args):
@@ -86,6 +87,8 @@ def call(name: str, *args):
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(lib(), name)
+    if CALL_LOG is not None:
+        CALL_LOG.append((name, args))
     if _TRACE:
         # SBR_TRACE_CALLS=1 (debug aid): name every entry point before it runs and wait for it, so that a device fault is
         # reported next to the launch that caused it
@@ -136,34 +139,6 @@ class pin_stream:
     def __exit__(self, *exc):
         _STREAM.value = self.prev
         return False
-
-
-class use_stream:
-    """Context manager: issue the kernel calls (and torch ops) inside on ``torch_stream`` — a second branch of a step. ``fork``
-    makes the branch start behind everything queued on the current stream so far; ``join()`` afterwards makes the current stream
-    wait for the branch. Inside a hipGraph capture this records a parallel branch of the graph."""
-
-    def __init__(self, torch_stream, fork: bool = True):
-        self.s, self.fork = torch_stream, fork
-
-    def __enter__(self):
-        import torch
-        self.cur = torch.cuda.current_stream()
-        if self.fork:
-            self.s.wait_stream(self.cur)
-        self.prev = _STREAM.value
-        self.ctx = torch.cuda.stream(self.s)
-        self.ctx.__enter__()
-        _STREAM.value = self.s.cuda_stream
-        return self
-
-    def __exit__(self, *exc):
-        _STREAM.value = self.prev
-        self.ctx.__exit__(*exc)
-        return False
-
-    def join(self):
-        self.cur.wait_stream(self.s)
 
 
 def to_device(t, device):

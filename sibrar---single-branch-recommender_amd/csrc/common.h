@@ -39,9 +39,13 @@ void sbr_set_error(const char* fmt, ...);
 #define SBR_SELU_ALPHA 1.6732632423543772848170429916717f
 #define SBR_SELU_SCALE 1.0507009873554804934193349852946f
 
+// torch.relu: a NaN stays a NaN ("x > 0 ? x : 0" — one v_max_f32 — would turn the NaN of an overflowed activation into a clean 0 and
+// hide the overflow from every later layer and from the loss)
+__device__ __forceinline__ float sbr_relu(float x) { return x < 0.f ? 0.f : x; }
+
 __device__ __forceinline__ float sbr_act(float x, int act) {
   switch (act) {
-    case SBR_ACT_RELU: return x > 0.f ? x : 0.f;
+    case SBR_ACT_RELU: return sbr_relu(x);
     case SBR_ACT_TANH: return tanhf(x);
     case SBR_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
     case SBR_ACT_SELU: return SBR_SELU_SCALE * (x > 0.f ? x : SBR_SELU_ALPHA * (expf(x) - 1.f));

@@ -449,6 +449,10 @@ extern "C" long sbr_gemm_tn_f32_workspace(int M, int N, int K) {
   return (long)splits * M * N * (long)sizeof(float);
 }
 
+// 1 when the product runs on the bf16 matrix pipe (gemm_split_tn_kernel: M = 128 i, N = 128 j, K >= 4096 and SBR_GEMM_SPLIT / SBR_TN_SPLIT
+// not 0), 0 when it stays on the fp32 ring kernel — what bench.py and the parity tests name the serving kernel by
+extern "C" int sbr_gemm_tn_split_supported(int M, int N, int K) { return sbr_tn_split_splits(M, N, K) > 0; }
+
 // slab pass of the TN product: partial tiles slab[z][M][N] for z < *splits_out (plain stores), no reduction
 static int tn_slabs(const float* A, long lda, const int* a_idx, const float* B, long ldb, const int* b_idx, int M, int N, int K,
                     void* workspace, long workspace_bytes, int* splits_out, hipStream_t s) {

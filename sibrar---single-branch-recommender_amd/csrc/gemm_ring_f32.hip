@@ -65,7 +65,7 @@ __device__ __forceinline__ void ring_store(f32x16 (&acc)[MI][2], float* __restri
                                            const float* bj, int act) {
   auto fin = [&](float v, int j) {
     if constexpr (KIND >= 1) v += bj[j];
-    if constexpr (KIND == 2) v = v > 0.f ? v : 0.f;
+    if constexpr (KIND == 2) v = sbr_relu(v);
     if constexpr (KIND == 3) v = sbr_act(v, act);
     return v;
   };

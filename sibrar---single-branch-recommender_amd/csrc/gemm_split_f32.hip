@@ -11,7 +11,9 @@
 // i.e. six bf16 MFMAs (products exact, fp32 accumulate) give the product to within one fp32 rounding of each term: the same
 // error class as the fp32 pipe's own accumulation, at 16 / 6 = 2.7x its rate.  The kernel below is therefore bound by HBM
 // (92 MB per product), not by the matrix pipe.  tests/test_hip_kernels.py::test_split_gemm_* measures the error against an fp64
-// product next to the fp32-pipe kernel's.  Non-finite inputs give NaN (inf - inf in the split) where the fp32 pipe gives inf.
+// product next to the fp32-pipe kernel's.  Non-finite inputs give NaN (inf - inf in the split) where the fp32 pipe gives inf: the
+// outputs such an operand poisons are the same on both pipes (its row / column), every other output keeps its bits, and the ReLU
+// epilogues keep a NaN a NaN (sbr_relu) — pinned by tests/test_hip_kernels.py::test_split_gemm_on_non_finite_operands.
 //
 // Layout of the work (no barrier after the set-up):
 //   * one workgroup of 8 waves per CU; the weight is split ONCE per workgroup into three bf16 planes that stay in LDS (96 KB) in
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
           const int lr = (r & 3) + 8 * (r >> 2);
           float v = acc[j][r];
           if constexpr (KIND <= 2) v += bj[j];
-          if constexpr (KIND == 1) v = v > 0.f ? v : 0.f;
+          if constexpr (KIND == 1) v = sbr_relu(v);
           if constexpr (KIND == 2) v = sbr_act(v, g.act);
           if constexpr (KIND == 3) {
             v = v * sbr_act_grad_from_out(yv[r], g.act);
@@ -542,7 +544,7 @@ _Pragma("unroll") \
         for (int r = 0; r < 16; ++r) { \
           const int lr = (r & 3) + 8 * (r >> 2); \
           float v = acc[j][r] + bj[j]; \
-          v = g.act == SBR_ACT_NONE ? v : (g.act == SBR_ACT_RELU ? (v > 0.f ? v : 0.f) : sbr_act(v, g.act)); \
+          v = g.act == SBR_ACT_NONE ? v : (g.act == SBR_ACT_RELU ? sbr_relu(v) : sbr_act(v, g.act)); \
           if (lr < rows_left) g.C[orow[r] * g.ldc + j * 32 + l31] = v; \
         } \
       } \

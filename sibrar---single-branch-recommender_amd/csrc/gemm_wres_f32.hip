@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wres_kernel(WresArgs g, int n_til
         for (int r = 0; r < 16; ++r) {
           float v = acc[j][r];
           if constexpr (KIND <= 2) v += bj[j];
-          if constexpr (KIND == 1) v = v > 0.f ? v : 0.f;
+          if constexpr (KIND == 1) v = sbr_relu(v);
           if constexpr (KIND == 2) v = sbr_act(v, g.act);
           if constexpr (KIND == 3) {
             const float4 y4 = yv[j][r >> 2];

@@ -7,19 +7,32 @@
 #include "common.h"
 
 __global__ void mask_scores_kernel(float* __restrict__ S, long ld, const long* __restrict__ u_idx,
-                                   const long* __restrict__ indptr, const int* __restrict__ indices, long Bu) {
+                                   const long* __restrict__ indptr, const int* __restrict__ indices, long Bu, int item_offset, int n_cols) {
   const long b = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= Bu) return;
   const long u = u_idx ? u_idx[b] : b;
-  for (long q = indptr[u] + (threadIdx.x & 63); q < indptr[u + 1]; q += 64) S[b * ld + indices[q]] = -INFINITY;
+  for (long q = indptr[u] + (threadIdx.x & 63); q < indptr[u + 1]; q += 64) {
+    const unsigned int c = (unsigned int)(indices[q] - item_offset);      // columns outside [item_offset, item_offset + n_cols): another shard's
+    if (c < (unsigned int)n_cols) S[b * ld + c] = -INFINITY;
+  }
 }
 
 extern "C" int sbr_mask_scores(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices,
                                long Bu, void* stream) {
   if (Bu == 0) return SBR_OK;
   SBR_REQUIRE(scores && excl_indptr && excl_indices, "sbr_mask_scores: null operand");
-  mask_scores_kernel<<<sbr_cdiv(Bu, 4), 256, 0, (hipStream_t)stream>>>(scores, ld, u_idx, excl_indptr, excl_indices, Bu);
+  mask_scores_kernel<<<sbr_cdiv(Bu, 4), 256, 0, (hipStream_t)stream>>>(scores, ld, u_idx, excl_indptr, excl_indices, Bu, 0, 0x7FFFFFFF);
   SBR_CHECK_LAUNCH("sbr_mask_scores");
+  return SBR_OK;
+}
+
+// the same for a score matrix that holds the item columns [item_offset, item_offset + n_cols) only (item-sharded evaluation)
+extern "C" int sbr_mask_scores_shard(float* scores, long ld, const long* u_idx, const long* excl_indptr, const int* excl_indices,
+                                     long Bu, int item_offset, int n_cols, void* stream) {
+  if (Bu == 0 || n_cols == 0) return SBR_OK;
+  SBR_REQUIRE(scores && excl_indptr && excl_indices && item_offset >= 0 && n_cols > 0, "sbr_mask_scores_shard: bad operand");
+  mask_scores_kernel<<<sbr_cdiv(Bu, 4), 256, 0, (hipStream_t)stream>>>(scores, ld, u_idx, excl_indptr, excl_indices, Bu, item_offset, n_cols);
+  SBR_CHECK_LAUNCH("sbr_mask_scores_shard");
   return SBR_OK;
 }
 

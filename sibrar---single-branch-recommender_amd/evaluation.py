@@ -21,7 +21,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
-from . import ops
+from . import ops, parallel
 
 SUPPORTED_METRICS = ('ndcg', 'precision', 'recall', 'f_score', 'hitrate', 'coverage')
 
@@ -247,7 +247,14 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     The users are scored in engine-sized chunks, not in the loader's batches: per-user results do not depend on the grouping,
     and the reference's default evaluation batch (256 users) leaves the GPU idle — the fused kernel assigns 448 users to a workgroup and every workgroup streams the whole catalogue, so they want >= 57k users per launch (measured on
     c2, 100k users, first kernel: 975 ms with 256-user batches, 37 ms with 8192, 12 ms in one launch); the fp32 path is bounded by the [chunk, items] score
-    matrix it materialises. ``user_chunk`` overrides the choice."""
+    matrix it materialises. ``user_chunk`` overrides the choice.
+
+    **Item-sharded under an initialised process group** (new: SURVEY.md 8(e), BASELINE configs[4] — the reference has no multi-GPU
+    path): rank r computes the representations of items [lo_r, hi_r) of the split only and scores every user chunk against them
+    (fused kernel with ``item_offset``, or fp32 GEMM + shard-aware mask + top-k); the per-shard ``[Bu, k]`` (score, item position)
+    lists are all-gathered and merged exactly (``parallel.all_gather_topk`` -> ``sbr_merge_topk``: score desc, index asc), and every
+    rank feeds the merged lists to its evaluator — all ranks return the same metrics as a one-rank evaluation. Models whose item side
+    is more than one matrix (biases) score unsharded on every rank."""
     dataset = eval_loader.dataset
     for attr in ('items_in_split', 'users_in_split', 'exclude_data'):
         if not hasattr(dataset, attr):
@@ -256,10 +263,23 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     kmax = max(evaluator._ks)
     with torch.no_grad():
         items = torch.as_tensor(np.asarray(dataset.items_in_split)).to(device)
-        i_repr = alg.get_item_representations(items)                          # once: [I_s, D] (or a tuple: embeddings, biases, ...)
+        n_split = int(items.shape[0])
+        world = parallel.world_size() if parallel.is_distributed() else 1
+        lo, hi = 0, n_split
+        sharded = False
+        if world > 1 and (world - 1) * (-(-n_split // world)) < n_split:      # every rank gets a non-empty shard
+            rank = torch.distributed.get_rank()
+            lo, hi = parallel.item_shard(n_split, rank, world)
+            probe = alg.get_item_representations(items[lo:hi])                # this rank's item shard only
+            sharded = torch.is_tensor(probe)
+            i_repr = probe if sharded else alg.get_item_representations(items)
+            if not sharded:
+                lo, hi = 0, n_split
+        else:
+            i_repr = alg.get_item_representations(items)                      # once: [I_s, D] (or a tuple: embeddings, biases, ...)
         plain = torch.is_tensor(i_repr)       # models whose item side is more than one matrix score through their own combine
         i_dev = i_repr.device if plain else i_repr[0].device
-        kmax = min(kmax, int(items.shape[0]))
+        kmax = min(kmax, n_split)
         excl = getattr(dataset, '_excl_dev', None)
         if excl is None or excl[0].device != i_dev:
             excl = _csr_to_device(dataset.exclude_data, i_dev)
@@ -274,7 +294,6 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
         if scorer == 'fp16_fused' and (not plain or kmax > 32 or i_repr.shape[1] not in (64, 128, 256)):
             # the fused kernel keeps at most 32 candidates per user on chip and is built for D in {64, 128, 256}: larger
             # cut-offs (the reference's default evaluator asks for top-100) take the exact fp32 GEMM + radix-select path
-            import logging
             logging.info(f'fp16_fused scorer: k={kmax}, item representation {"tuple" if not plain else tuple(i_repr.shape)} outside '
                          f'the fused kernel, using the fp32 path')
             scorer = 'fp32'
@@ -284,16 +303,25 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
         elif scorer == 'fp16_fused':
             bs = max(bs, 262144)                                    # one launch for up to 256k users (fp16 rows: 64 MB at D = 128)
         else:
-            bs = max(bs, min(16384, max(1, (1 << 31) // max(int(items.shape[0]), 1))))      # <= 8 GiB of fp32 scores per chunk
+            bs = max(bs, min(16384, max(1, (1 << 31) // max(hi - lo, 1))))      # <= 8 GiB of fp32 scores per chunk
         for s in range(0, len(users), bs):
             u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
             u_repr = alg.get_user_representations(u_idxs)
             if scorer == 'fp16_fused' and torch.is_tensor(u_repr):
-                _, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1])
+                val, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1], item_offset=lo)
             else:
                 out = alg.combine_user_item_representations(u_repr, i_repr)
-                ops.mask_scores_(out, u_idxs, excl[0], excl[1])
-                _, idx = ops.topk_rows(out, kmax)
+                ops.mask_scores_(out, u_idxs, excl[0], excl[1], item_offset=lo if sharded else None)
+                kl = min(kmax, hi - lo)
+                val, idx = ops.topk_rows(out, kl)
+                if sharded:
+                    idx = idx + lo                                  # positions in items_in_split
+                    if kl < kmax:                                   # a shard shorter than the list: empty slots behind its items
+                        pad = (idx.shape[0], kmax - kl)
+                        val = torch.cat([val, torch.full(pad, -float('inf'), device=val.device)], 1)
+                        idx = torch.cat([idx, torch.full(pad, -1, device=idx.device, dtype=idx.dtype)], 1)
+            if sharded:
+                val, idx = parallel.all_gather_topk(val, idx, kmax)
             evaluator.eval_topk(u_idxs, idx)
         if hasattr(alg, 'check_index_errors'):
             alg.check_index_errors()

@@ -77,6 +77,7 @@ def gemm(mode: int, A, lda, a_idx, B, ldb, b_idx, bias, C, ldc, c_idx, M, N, K, 
 
 import os as _os
 
+_WRES = True                    # weights-resident kernel for N = K = 128 products below the bf16-split kernel's row threshold (tests switch it)
 # fp32 products on the bf16 matrix pipe over exact three-way operand splits (csrc/gemm_split_f32.hip); '0' keeps every product on
 # the fp32 pipe (v_mfma_f32_32x32x2_f32)
 _SPLIT = _os.environ.get('SBR_GEMM_SPLIT', '1') != '0'
@@ -93,7 +94,7 @@ def _mlp_kernel(M, N, K) -> str:
 def _wres_ok(M, N, K, *tensors) -> bool:
     """The weights-resident kernel (csrc/gemm_wres_f32.hip) takes the shared MLP's own products: N = K = 128, no gathers,
     16-byte aligned rows."""
-    if M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
+    if not _WRES or M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
         return False
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
 
@@ -682,9 +683,14 @@ def infonce_max_n() -> int:
 
 
 # ---- evaluation helpers -----------------------------------------------------------------------------------------------------
-def mask_scores_(scores: torch.Tensor, u_idx: torch.Tensor, excl_indptr: torch.Tensor, excl_indices: torch.Tensor):
+def mask_scores_(scores: torch.Tensor, u_idx: torch.Tensor, excl_indptr: torch.Tensor, excl_indices: torch.Tensor, item_offset: int = None):
+    """``item_offset`` (item-sharded evaluation): ``scores`` holds the item columns [item_offset, item_offset + scores.shape[1])."""
     _need_cuda(scores)
-    call('sbr_mask_scores', ptr(scores), scores.stride(0), ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), scores.shape[0], stream())
+    if item_offset is None:
+        call('sbr_mask_scores', ptr(scores), scores.stride(0), ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), scores.shape[0], stream())
+    else:
+        call('sbr_mask_scores_shard', ptr(scores), scores.stride(0), ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), scores.shape[0],
+             int(item_offset), int(scores.shape[1]), stream())
     return scores
 
 

@@ -817,6 +817,46 @@ def test_split_gemm_has_the_error_of_the_fp32_pipe(M, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('where', ['activation', 'weight'])
+def test_split_gemm_on_non_finite_operands(where, monkeypatch):
+    """Documented deviation of the bf16-split kernels (csrc/gemm_split_f32.hip header): an infinite operand gives NaN where the fp32
+    pipe (and torch) give +-inf — the split x = x0 + x1 + x2 computes inf - inf. What is pinned: a non-finite operand poisons EXACTLY
+    the outputs it poisons on the fp32 pipe (the row of an infinite activation, the column of an infinite weight: every such output
+    is non-finite in both), and every other output keeps the bits of the clean product — a step that has overflowed is non-finite
+    in the loss either way (train/trainer.py:215-219 reports it), nothing finite is silently changed."""
+    ops = S().ops
+    monkeypatch.setattr(ops, '_SPLIT_MIN_ROWS', 1)
+    M = 4100
+    x, w, b = _rand(M, 128, seed=5).to(DEV), (_rand(128, 128, seed=6) / 8).to(DEV), _rand(128, seed=7).to(DEV)
+    xk, wk = _rand(M, 768, seed=8).to(DEV), (_rand(128, 768, seed=9) / 16).to(DEV)
+    def run(x_, w_, xk_, wk_):
+        out = {}
+        for flag in (True, False):
+            monkeypatch.setattr(ops, '_SPLIT', flag)
+            out[flag] = [ops.linear_nt(x_, w_, b, 1), ops.matmul_nn(x_, w_), ops.linear_nt(xk_, wk_, b, 0)]
+        return out
+    clean = run(x, w, xk, wk)
+    x2, w2, xk2, wk2 = x.clone(), w.clone(), xk.clone(), wk.clone()
+    if where == 'activation':
+        x2[17, 3], x2[4099, 127], xk2[17, 700] = float('inf'), float('-inf'), float('inf')
+        bad = lambda t, which: (torch.zeros_like(t, dtype=torch.bool).index_fill_(0, torch.tensor([17, 4099] if which < 2 else [17], device=DEV), True))
+    else:
+        w2[5, 9], wk2[5, 9] = float('inf'), float('inf')
+        # NT: W[n, k] -> output column n = 5; NN: W[k, n] -> output column n = 9
+        bad = lambda t, which: (torch.zeros_like(t, dtype=torch.bool).index_fill_(1, torch.tensor([9 if which == 1 else 5], device=DEV), True))
+    dirty = run(x2, w2, xk2, wk2)
+    for which in range(3):
+        m = bad(clean[True][which], which)
+        for flag in (True, False):
+            d, c = dirty[flag][which], clean[flag][which]
+            if which == 0 and not flag:                               # relu epilogue on the fp32 pipe: relu(-inf) = 0, as in torch
+                assert bool((~torch.isfinite(d[m]) | (d[m] == 0)).all()) and not bool(torch.isfinite(d[m]).all())
+            else:                                                     # (relu keeps a NaN a NaN: sbr_relu, torch.relu)
+                assert not bool(torch.isfinite(d[m]).any()), (which, flag)
+            assert torch.equal(d[~m], c[~m]), (which, flag)           # untouched outputs: the bits of the clean product
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,K', [(4096, 768), (5000, 256), (9001, 1024), (45801, 256), (36000, 256), (52000, 256), (70001, 256)])
 def test_split_projector_gemm_has_the_error_of_the_fp32_pipe(M, K, monkeypatch):
     """sbr_gemm_split_proj_f32 (the dense modality projector on the bf16 matrix pipe: K walked in chunks of 128, row gather and row

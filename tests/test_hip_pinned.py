@@ -418,6 +418,85 @@ def test_c3_step_at_full_shapes_against_the_cpu_oracle():
     fused.close()
 
 
+def test_c2_step_at_the_bench_batch_against_the_cpu_oracle():
+    """BASELINE configs[1] exactly as ``bench.py`` times it: the bench's model (bench.build), one loader batch of 8,192 interactions
+    x 11 slots with its recorded modality draw, ``FusedTrainStep.step`` three times — plain launches, hipGraph capture + replay,
+    replay — with the optimizer launch replaced by a recorder, against the CPU oracle (oracle/model_ref.py restating
+    train/trainer.py:204-223 -> sgd_alg.py:2116-2125, rec_losses.py:88-113) on the same parameters, batch and draw: the
+    sampled-softmax loss (1e-4 relative) and EVERY gradient incl. both embedding tables (norm-wise 1e-4). The call log of the
+    plain-launch pass must show the launch mix the bench line is timed on: bf16-split projector, bf16-split K = N = 128 products
+    (forward with the BatchNorm statistics epilogue, backward), bf16-split dW products, the fused scorer + loss + statistics kernel,
+    the one-launch lookup."""
+    import importlib
+    from oracle import losses_ref, model_ref
+    bench = importlib.import_module('bench')
+    _lib = importlib.import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    ds, net = bench.build(S(), dict(bench.C2), DEV)
+    net.train()
+    cfg = bench.model_config(bench.C2['emb_dim'])
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and 'running' not in k:
+            v.requires_grad_(True)
+    opt = S().FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=0.)
+    lossf = S().RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                                      neg_train=ds.n_negative_samples)
+    fused = S().FusedTrainStep(net, lossf, opt, use_graph=True)
+    seen = []
+    def _record(*a, **k):                                      # stands in for the optimizer launch (which also resets the gradient)
+        seen.append({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
+        if k.get('zero_grad'):
+            opt.fp.grad.zero_()
+        return False
+    opt.step_flat = _record
+    np.random.seed(42)
+    loader = S().NegativeSamplingDataLoader(ds, batch_size=8192, shuffle=True)
+    u, i, labels = next(iter(loader))
+    assert tuple(i.shape) == (8192, 11)
+    draws = fused.draw(u.shape, i.shape)
+    recs = []
+    for rep in range(3):
+        if rep == 0:
+            _lib.CALL_LOG = []
+        total, rec, reg = fused.step(u, i, labels, draws)
+        if rep == 0:
+            log, _lib.CALL_LOG = _lib.CALL_LOG, None
+        recs.append(rec.cpu())
+    assert fused.n_replays == 2
+    # ---- the launch mix of the timed path
+    names = [n_ for n_, _ in log]
+    lib = _lib.lib()
+    assert names.count('sbr_gemm_split_proj_f32') == 1, names                       # projector forward 45k x 128 x 768, gathered
+    assert names.count('sbr_gemm_split_bnstats_f32') == 1                           # last Linear + BatchNorm statistics + finalisation
+    assert names.count('sbr_gemm_split_f32') >= 1                                   # dX of the shared layer (K = N = 128)
+    assert 'sbr_gemm_wres_f32' not in names and 'sbr_gemm_f32' not in names         # nothing on the fp32 pipe
+    tn = [a for n_, a in log if n_ == 'sbr_gemm_tn_f32_slabs']
+    assert len(tn) == 3 and all(lib.sbr_gemm_tn_split_supported(int(a[6]), int(a[7]), int(a[8])) for a in tn), tn
+    assert names.count('sbr_bn_score_loss_fwd_bwd') == 1 and names.count('sbr_bn_score_bwd_apply') == 1
+    assert names.count('sbr_lookup_rows') == 1 and 'sbr_rec_loss_fwd_bwd' not in names
+    # ---- the oracle on the same inputs
+    pos, order = draws[1]
+    mods = np.array(order)[pos].reshape(tuple(i.shape) + (1,))
+    ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
+    it = {'text': model_ref.table_from_feature(ds.item_features['text']),
+          'item_embedding': model_ref.RefTable('categorical', np.arange(ds.n_items), n_categories=ds.n_items)}
+    ref = model_ref.RefSingleBranchNet(sd, cfg, ut, it, orders={'item_train': net.item_embedding_module.train_modality_order,
+                                                                'item_eval': net.item_embedding_module.eval_modality_order})
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    logits = ref.forward(u, i, True, None, mods)
+    rl = losses_ref.RefRecLoss('sampled_softmax', n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
+                               neg_train=ds.n_negative_samples).compute_loss(logits, labels)
+    rl.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    assert {'user_embedding_module.embedding_layer.weight'} <= set(grads) and len(grads) == len(seen[0])
+    sc = gscale(grads.values())
+    for rep in range(3):
+        close(recs[rep], rl.detach().double(), what=f'rec loss (pass {rep})', rtol=1e-4, atol=1e-7)
+        for k_, g in grads.items():
+            close(seen[rep][k_].cpu(), g, what=f'grad {k_} (pass {rep})', rtol=2e-4, atol=1e-7, scale=sc, norm_rtol=1e-4)
+    fused.close()
+
+
 def test_c4_step_on_one_gpu_at_full_table_shapes():
     """BASELINE configs[3] on ONE GPU (the 8-GPU job runs this per rank): 1M users x 200k items, text 768 + image 2048, C = D =
     256, user = embedding lookup (257 M parameters, 1 GB user table), sampled softmax, batch 256.
@@ -714,3 +793,29 @@ def test_two_rank_data_parallel_parity_with_the_oracle(case_name, sparse, tmp_pa
         for k, v in stats[r].items():
             if k not in skip:
                 close(got[r][k], v, what=f'rank {r} {k}', rtol=2e-4, atol=2e-5, norm_rtol=1e-4)
+
+
+def test_two_rank_item_sharded_evaluation_equals_one_rank(tmp_path):
+    """``evaluate_recommender_algorithm`` under a 2-rank process group (item-sharded: eval/eval.py:203-222 with BASELINE configs[4]'s
+    sharding — each rank the representations and scores of its item shard, all-gather + exact merge of the top-k lists, metrics on
+    every rank) returns on BOTH ranks, user by user, what the one-rank evaluation returns: the golden G9 world (fp32 route) and a
+    3,000 x 1,111 world with D = 64 (fused kernel with item_offset), both scorers. See tests/dp_eval_worker.py."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    prefix = str(tmp_path / 'ev')
+    def launch(world):
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, 'dp_eval_worker.py'), str(r), str(world), str(tmp_path / f'rdzv{world}'), prefix],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), '\n'.join(l[-2000:] for l in logs)
+        return [np.load(prefix + f'.w{world}.rank{r}.npz') for r in range(world)]
+    one = launch(1)[0]
+    two = launch(2)
+    assert len(one.files) > 20
+    for r in range(2):
+        assert sorted(two[r].files) == sorted(one.files)
+        for k in one.files:
+            assert np.array_equal(two[r][k], one[k]), f'rank {r}: {k} differs from the one-rank evaluation'
+

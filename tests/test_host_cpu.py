@@ -206,6 +206,18 @@ v, i = torch.topk(scores[:, lo:hi], 5, sorted=True)
 mv, mi = S.parallel.all_gather_topk(v, (i + lo).int(), 5)
 tv, ti = torch.topk(scores, 5, sorted=True)
 assert torch.equal(mv, tv) and torch.equal(mi.long(), ti)
+# (4) the assembly of evaluation.evaluate_recommender_algorithm for a shard SHORTER than the list (5 items over 2 ranks, top-4):
+# empty slots (-inf, -1) behind a shard's items, merged lists == global top-4 with positions in items_in_split
+small = torch.randn(16, 5, generator=gen)
+lo, hi = S.parallel.item_shard(5, rank, world)
+kl = min(4, hi - lo)
+v, i = torch.topk(small[:, lo:hi], kl, sorted=True)
+i = (i + lo).int()
+v = torch.cat([v, torch.full((16, 4 - kl), -float('inf'))], 1)
+i = torch.cat([i, torch.full((16, 4 - kl), -1, dtype=torch.int32)], 1)
+mv, mi = S.parallel.all_gather_topk(v, i, 4)
+tv, ti = torch.topk(small, 4, sorted=True)
+assert torch.equal(mv, tv) and torch.equal(mi.long(), ti)
 dist.barrier()
 print('rank', rank, 'ok')
 '''
