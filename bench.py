@@ -153,46 +153,84 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     return dt, timings
 
 
+def gemm_bytes(mode, M, N, K):
+    """Algorithmic HBM bytes of one GEMM launch (fp32 operands read once, result written once; NN in the backward pass also reads the
+    activation whose derivative its epilogue applies — counted by the caller where it applies)."""
+    return 4.0 * ((M * K + N * K + M * N) if mode != 2 else (K * M + K * N + M * N))
+
+
+def gemm_price(mode, M, N, K, gathered, avg_ms):
+    """Honest pricing of one GEMM signature: the bound is the larger of the time the kernel's OWN matrix pipe needs and the time HBM
+    needs for the algorithmic bytes. A bf16-split kernel issues 6 bf16 MFMA terms per fp32 multiply-add, so its pipe time is
+    6 * 2 M N K / 2.5 PFLOP/s (not 2 M N K against the fp32 peak: that ratio can exceed 1). ``frac`` = bound time / measured time <= 1
+    for any kernel that does the work."""
+    sym, what, terms, pipe = gemm_kernel(mode, M, N, K, gathered)
+    flop = 2.0 * M * N * K
+    t = avg_ms * 1e-3
+    peak_pipe = PEAK_MFMA_F16 if pipe == 'bf16' else PEAK_MFMA_F32
+    t_pipe = flop * terms / (peak_pipe * 1e12)
+    byts = gemm_bytes(mode, M, N, K)
+    t_hbm = byts / (PEAK_HBM * 1e9)
+    if t_pipe >= t_hbm:
+        bound, achieved, peak, unit = 'mfma', flop * terms / t / 1e12, peak_pipe, 'TFLOP/s'
+    else:
+        bound, achieved, peak, unit = 'hbm', byts / t / 1e9, PEAK_HBM, 'GB/s'
+    return {'bound': bound, 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit, 'frac': round(max(t_pipe, t_hbm) / t, 4),
+            'pipe': ('bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 terms per fp32 multiply-add' if pipe == 'bf16'
+                     else 'fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
+            'pipe_frac': round(t_pipe / t, 4), 'hbm_frac': round(t_hbm / t, 4), 'algorithmic_flop': flop, 'algorithmic_bytes': byts,
+            'fp32_equivalent_tflops': round(flop / t / 1e12, 2), 'served_by': sym.strip().rstrip(',').strip(), 'what': what}
+
+
 def gemm_table(timings, steps):
-    """Every GEMM signature of the step, HIP-event timed: [{kernel, launches_per_step, avg_launch_ms, TFLOP/s, frac}] by time."""
+    """Every GEMM signature of the step, HIP-event timed, priced by ``gemm_price``; by time per step."""
     rows = []
     for key, ts in timings.items():
         if key[0] != 'gemm_f32' or not ts:
             continue
         _, mode, M, N, K, gathered = key
         avg_ms = sum(ts) / len(ts)
-        tf = 2.0 * M * N * K / (avg_ms * 1e-3) / 1e12
-        sym, _what, terms, pipe = gemm_kernel(mode, M, N, K, gathered)
+        p = gemm_price(mode, M, N, K, gathered, avg_ms)
         rows.append({'kernel': f'{["NT", "NN", "TN"][mode]} M={M} N={N} K={K}' + (' gathered' if gathered else ''),
-                     'served_by': sym.strip().rstrip(',') + (' (bf16 pipe, 6 terms)' if pipe == 'bf16' else ' (fp32 pipe)'),
-                     'launches_per_step': round(len(ts) / steps, 2), 'avg_launch_ms': round(avg_ms, 4),
-                     'ms_per_step': round(sum(ts) / steps, 4), 'tflops': round(tf, 2), 'frac': round(tf / PEAK_MFMA_F32, 4)})
+                     'served_by': p['served_by'], 'launches_per_step': round(len(ts) / steps, 2), 'avg_launch_ms': round(avg_ms, 4),
+                     'ms_per_step': round(sum(ts) / steps, 4), 'bound': p['bound'], 'frac': p['frac'], 'pipe_frac': p['pipe_frac'],
+                     'hbm_frac': p['hbm_frac'], 'fp32_equivalent_tflops': p['fp32_equivalent_tflops']})
     return sorted(rows, key=lambda r: -r['ms_per_step'])
 
 
 def gemm_kernel(mode, M, N, K, gathered):
     """-> (kernel symbol as the kernel trace names it, what it is, MFMA terms per fp32 multiply-add, pipe) of the launch that serves
-    this GEMM signature — the same decisions as ops.linear_nt / matmul_nn / matmul_tn and csrc/gemm_f32.hip take."""
+    this GEMM signature — asked of the library's own predicates (the decisions ops.linear_nt / matmul_nn / matmul_tn take)."""
     import importlib
     ops = importlib.import_module('sibrar_amd').ops
     lib = importlib.import_module(ops.__name__.rsplit('.', 1)[0] + '._lib').lib()
-    env = os.environ
     split = bool(getattr(ops, '_SPLIT', False))
     if mode == 2:
-        on = split and env.get('SBR_TN_SPLIT', '1') != '0' and M >= 128 and M % 128 == 0 and N >= 128 and N % 128 == 0 and K >= 4096
-        if on:
+        if split and lib.sbr_gemm_tn_split_supported(int(M), int(N), int(K)):
             return (f'void gemm_split_tn_kernel<{"true" if (N // 128) * (M // 128) > 1 else "false"}>', 'bf16-split dW kernel (csrc/gemm_split_tn_f32.hip)', 6, 'bf16')
         return ('void gemm_ring_kernel<1, true, true, 2>', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
-    rows = M
-    if split and rows >= getattr(ops, '_SPLIT_MIN_ROWS', 4096):
+    if split and M >= getattr(ops, '_SPLIT_MIN_ROWS', 4096):
         if mode == 0 and gathered and lib.sbr_gemm_split_proj_supported(int(M), int(N), int(K)):
             return ('gemm_split_proj_kernel', 'bf16-split projector kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
         if lib.sbr_gemm_split_supported(int(M), int(N), int(K)):
-            return (f'void gemm_split_kernel<{mode}, ', 'bf16-split K = N = 128 kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
+            return (f'void gemm_split_kernel<{mode}, ', 'bf16-split shared-MLP kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
     return ('void gemm_ring_kernel<', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
 
 
 PMC_SCORER_PREFIX = '_Z23score_topk_f16_n_kernel'        # fused scorer dispatches in the same PMC passes (the only launches of that kernel there)
+# entry point -> kernel symbol of the kernel trace / PMC summaries, for the kernels that are no GEMMs
+ENTRY_KERNEL = {'sbr_adam_step_zero_grad': 'void adamw_kernel<true>', 'sbr_adam_step': 'void adamw_kernel<false>'}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources the library was built from (the PMC summary records the one it was collected with)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, 'sibrar---single-branch-recommender_amd', 'csrc', '*.h*'))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def _pmc_file():
@@ -203,40 +241,64 @@ def _pmc_file():
 
 
 def _pmc_rows():
+    """-> (relative path, csrc hash the summary was collected with | None, rows)"""
     import csv
+    import re
     path = _pmc_file()
     if path is None:
-        return None, []
-    return os.path.relpath(path, ROOT), list(csv.reader(l for l in open(path) if not l.startswith('#')))
+        return None, None, []
+    lines = open(path).read().splitlines()
+    sha = next((m.group(1) for l in lines if l.startswith('#') for m in [re.search(r'csrc_sha16=([0-9a-f]{16})', l)] if m), None)
+    return os.path.relpath(path, ROOT), sha, list(csv.reader(l for l in lines if not l.startswith('#')))
 
 
-def pmc_traffic(mode, M, N, K, batch, gathered=False):
-    """HBM bytes per launch of a GEMM signature from the committed PMC summary (None when the run is not the profiled shape, or when
-    the summary predates the kernel that serves the signature now)."""
-    if batch != 8192:
+def pmc_symbol_traffic(sym, batch, one_shape=True):
+    """HBM bytes per launch of a kernel symbol from the committed PMC summary -> (bytes | None, note). The PMC counters cannot be
+    read inside this process (they need rocprofv3 around it), so the figure is QUOTED from the summary of the same command; the note
+    says which summary, and whether the kernel sources have changed since it was collected."""
+    if batch != 8192 or sym is None:
         return None, None
-    sym = gemm_kernel(mode, M, N, K, gathered)[0]
-    path, rows = _pmc_rows()
+    path, sha, rows = _pmc_rows()
     if path is None:
         return None, None
     hit = [(float(r[2]), float(r[5])) for r in rows if len(r) >= 6 and r[0].startswith(sym)]
-    if sym.startswith('void gemm_ring_kernel<1, true') and len(hit) > 1:
-        return None, None                          # two TN shapes behind one ring symbol: not attributable
     n = sum(h[0] for h in hit)
-    if not hit or n == 0:
+    if not hit or n == 0 or (one_shape and sym.startswith('void gemm_ring_kernel<1, true') and len(hit) > 1):
         return None, None
-    return sum(h[0] * h[1] for h in hit) / n * 1e6, path
+    cur = csrc_sha16()
+    note = (f'HBM bytes per launch quoted from {path} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, gfx950 '
+            f'correction of MI355X_MICROARCH.md); ' +
+            ('collected with the kernel sources of this run' if sha == cur else
+             f'STALE: collected with kernel sources {sha or "unrecorded"}, this run has {cur}'))
+    return sum(h[0] * h[1] for h in hit) / n * 1e6, note
 
 
 def pmc_scorer_traffic(n_users):
     """HBM bytes of one fused scoring launch over the c2 catalogue from the same PMC passes (None for another shape)."""
-    path, rows = _pmc_rows()
+    path, sha, rows = _pmc_rows()
     if path is None or n_users != C2['n_users']:
         return None, None
     for r in rows:
         if r[0].startswith(PMC_SCORER_PREFIX):
-            return float(r[5]) * 1e6, path
+            cur = csrc_sha16()
+            return float(r[5]) * 1e6, path + ('' if sha == cur else f' [STALE: kernel sources {sha or "unrecorded"} vs {cur}]')
     return None, None
+
+
+def kernel_table(timings, steps):
+    """Every C-ABI entry point of the step by time per step (HIP events around every call of K plain-launch steps)."""
+    rows = []
+    for key, ts in timings.items():
+        if key[0] != 'call' or not ts:
+            continue
+        rows.append({'entry_point': key[1], 'launches_per_step': round(len(ts) / steps, 2), 'avg_launch_ms': round(sum(ts) / len(ts), 4),
+                     'ms_per_step': round(sum(ts) / steps, 4)})
+    return sorted(rows, key=lambda r: -r['ms_per_step'])
+
+
+TIMING_NOTE = ('HIP events around every launch over K plain-launch steps run right after the timed region (the timed region replays a '
+               'hipGraph, which cannot carry per-kernel events); each of those steps is queued behind a spin kernel so that its '
+               'kernels run back to back as they do in the replay')
 
 
 def dominant_gemm(timings, steps, batch=None):
@@ -264,36 +326,89 @@ def dominant_gemm(timings, steps, batch=None):
             if mine:
                 reduce_ms += (sum(rts) / len(rts)) * mine / total / max(1, sum(1 for (m, n, z) in key[1] if (m, n) == (M, N)))
         avg_ms += reduce_ms
-    flops = 2.0 * M * N * K
-    achieved = flops / (avg_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(mode, M, N, K, batch, gathered)
-    sym, what, terms, pipe = gemm_kernel(mode, M, N, K, gathered)
-    out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-           'frac': round(achieved / PEAK_MFMA_F32, 4), 'traffic': traffic,
-           'traffic_source': None if traffic is None else f'HBM bytes per launch from {src} (rocprofv3 --pmc FETCH_SIZE and --pmc '
-                             f'WRITE_SIZE passes of this command, gfx950 correction of MI355X_MICROARCH.md)',
-           'kernel': f'{what}: {sym.strip()}, mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
-                     + (f' + its share ({reduce_ms * 1e3:.1f} us, by slab bytes) of the step\'s shared split-K slab reduction '
-                        f'(splitk_reduce_multi_kernel)' if mode == 2 else ''),
-           'pricing': 'achieved = algorithmic fp32 FLOP (2 M N K) / launch time, peak = the fp32 MFMA peak (the arithmetic the path '
-                      'computes in is fp32: `dtype`)'}
-    if pipe == 'bf16':
-        # the product is computed exactly enough for fp32 by SIX bf16 MFMA terms per multiply-add (three-way exact operand split):
-        # on the pipe it actually runs on the kernel issues 6 x the algorithmic FLOP
-        out['pipe'] = {'name': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 terms per fp32 multiply-add', 'achieved': round(achieved * terms, 1),
-                       'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s', 'frac': round(achieved * terms / PEAK_MFMA_F16, 4)}
-    out.update({
-            'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts), 'kernel_ms_per_step': round(tot / steps + reduce_ms * len(ts) / steps, 4),
-            'timing': 'HIP events around every launch of this kernel over K plain-launch steps run right after the timed '
-                      'region (the timed region replays a hipGraph, which cannot carry per-kernel events); each of those steps '
-                      'is queued behind a spin kernel so that its kernels run back to back as they do in the replay',
-            'all_gemms': gemm_table(timings, steps)})
+    out = gemm_price(mode, M, N, K, gathered, avg_ms)
+    traffic, note = pmc_symbol_traffic(out['served_by'], batch)
+    out.update({'traffic': traffic, 'traffic_source': note,
+                'kernel': f'{out.pop("what")}: {out["served_by"]}, mode={["NT","NN","TN"][mode]} M={M} N={N} K={K} gather={bool(gathered)}'
+                          + (f' + its share ({reduce_ms * 1e3:.1f} us, by slab bytes) of the step\'s shared split-K slab reduction '
+                             f'(splitk_reduce_multi_kernel)' if mode == 2 else ''),
+                'avg_launch_ms': round(avg_ms, 4), 'launches': len(ts),
+                'kernel_ms_per_step': round(tot / steps + reduce_ms * len(ts) / steps, 4), 'timing': TIMING_NOTE})
     return out
+
+
+def step_roofline(timings, steps, batch, n_params):
+    """The ``roofline`` object of the line: the kernel with the largest time per step over ALL kernels of the step (GEMM signatures
+    and every other entry point), priced on the resource that bounds it; the largest GEMM rides along as ``dominant_gemm``."""
+    gemm = dominant_gemm(timings, steps, batch)
+    calls = kernel_table(timings, steps)
+    gemm_entries = {'sbr_gemm_f32', 'sbr_gemm_split_f32', 'sbr_gemm_split_bnstats_f32', 'sbr_gemm_split_proj_f32', 'sbr_gemm_wres_f32',
+                    'sbr_gemm_nt_splitk_f32', 'sbr_gemm_tn_f32', 'sbr_gemm_tn_f32_slabs'}
+    other = [r for r in calls if r['entry_point'] not in gemm_entries]
+    out = None
+    if other and (gemm is None or other[0]['ms_per_step'] > gemm['kernel_ms_per_step']):
+        top = other[0]
+        name = top['entry_point']
+        if name in ('sbr_adam_step_zero_grad', 'sbr_adam_step') and n_params:
+            # dense AdamW (train/trainer.py:62-68 -> optimizer.step(), zero_grad()): reads p, g, m, v and writes p, m, v = 28 bytes per
+            # parameter (the gradient reset only writes elements that are not +0 already)
+            byts = 28.0 * n_params
+            t = top['avg_launch_ms'] * 1e-3
+            traffic, note = pmc_symbol_traffic(ENTRY_KERNEL.get(name), batch)
+            out = {'bound': 'hbm', 'achieved': round(byts / t / 1e9, 1), 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': round(byts / t / 1e9 / PEAK_HBM, 4),
+                   'traffic': traffic, 'traffic_source': note, 'algorithmic_bytes': byts,
+                   'kernel': f'{ENTRY_KERNEL.get(name)} ({name}): dense AdamW over all {n_params} parameters + gradient reset + loss read-out, '
+                             f'28 bytes per parameter', 'avg_launch_ms': top['avg_launch_ms'], 'kernel_ms_per_step': top['ms_per_step'],
+                   'timing': TIMING_NOTE}
+    if out is None:
+        out = dict(gemm) if gemm else None
+    if out is not None:
+        out['selection'] = 'largest time per step over ALL kernels of the step (GEMM signatures and every other entry point)'
+        if gemm is not None and out.get('kernel') != gemm.get('kernel'):
+            out['dominant_gemm'] = gemm
+        out['all_gemms'] = gemm_table(timings, steps)
+        out['all_kernels'] = calls[:16]
+    return out
+
+
+def _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm):
+    import torch.distributed as dist
+    for _ in range(warm):                                # the chip's clock settles over the first few passes of a burst
+        S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+    S.ops.KernelTimer.reset(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+        if world > 1:
+            val, idx = S.parallel.all_gather_topk(val, idx, k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    res = S.ops.KernelTimer.results()
+    S.ops.KernelTimer.reset(False)
+    ts = [t for key, v in res.items() if key[0] == 'score_topk_f16' for t in v]
+    if world > 1:
+        t = torch.tensor([dt], device=u16.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, sum(ts) / len(ts)
+
+
+def scoring_roofline(n_users, n_items, D, k, avg_ms, traffic=None, traffic_source=None, kernel=None):
+    flops = 2.0 * n_users * n_items * D
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_MFMA_F16, 4),
+            'traffic': traffic, 'traffic_source': traffic_source,
+            'algorithmic_bytes': (n_users + n_items) * D * 2 + n_users * k * 8,
+            'kernel': kernel or 'fused fp16 scorer: sbr_score_topk_f16 (every launch of the call)', 'avg_launch_ms': round(avg_ms, 4)}
 
 
 def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):
     """Full-catalogue scoring with the fused fp16 kernel: all users x all items (item-sharded over ranks), top-k."""
-    import torch.distributed as dist
     net.eval()
     with torch.no_grad():
         i_repr = net.get_item_representations(torch.arange(ds.n_items, device=device))
@@ -302,40 +417,33 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):
         users = torch.arange(ds.n_users, device=device)
         u16 = S.ops.cast_f16(net.get_user_representations(users))
         excl = S.evaluation._csr_to_device(ds.user_sampling_matrix_train, device)
-        for _ in range(warm):                                # the chip's clock settles over the first few passes of a burst
-            S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
-        S.ops.KernelTimer.reset(True)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
-            if world > 1:
-                val, idx = S.parallel.all_gather_topk(val, idx, k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = (time.perf_counter() - t0) / reps
-        ts = [t for key, v in S.ops.KernelTimer.results().items() if key[0] == 'score_topk_f16' for t in v]
-        S.ops.KernelTimer.reset(False)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    avg_ms = sum(ts) / len(ts)
-    flops = 2.0 * ds.n_users * (hi - lo) * i16.shape[1]
-    achieved = flops / (avg_ms * 1e-3) / 1e12
+        dt, avg_ms = _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm)
+    tr, src = pmc_scorer_traffic(ds.n_users) if world == 1 else (None, None)
     return {'metric': 'full-catalogue scores/s (fused fp16 score+mask+top-20)', 'value': ds.n_users * ds.n_items / dt,
             'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
-            'sharding': f'items/{world}',
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_MFMA_F16, 4),
-                         'traffic': pmc_scorer_traffic(ds.n_users)[0] if world == 1 else None,
-                         'traffic_source': pmc_scorer_traffic(ds.n_users)[1] if world == 1 else None,
-                         'algorithmic_bytes': (ds.n_users + (hi - lo)) * int(i16.shape[1]) * 2 + ds.n_users * k * 8,
-                         'kernel': 'score_topk_f16_n_kernel (+ the three event-builder launches of the call: exclusion CSR -> per-wave event stream)',
-                         'avg_launch_ms': round(avg_ms, 4)}}
+            'sharding': f'items/{world}', 'exclusions': int(excl[1].numel()),
+            'roofline': scoring_roofline(ds.n_users, hi - lo, int(i16.shape[1]), k, avg_ms, tr, src)}
+
+
+def bench_c5_shard(S, device, k=20, reps=12, warm=6):
+    """BASELINE configs[4], ONE of its eight item shards at its own size on one GPU: 100k users x 25k items x 256 fp16 N(0, 1)/16
+    representations, 50 excluded items per user, top-20 — what every rank of the 8-GPU job runs per 100k users."""
+    g = torch.Generator(device='cpu').manual_seed(5)
+    U, I, D = 100_000, 25_000, 256
+    u16 = (torch.randn(U, D, generator=g) / 16).half().to(device)
+    i16 = (torch.randn(I, D, generator=g) / 16).half().to(device)
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.integers(0, I, size=(U, 50)), axis=1)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((np.ones(U * 50, dtype=np.int8), cols.reshape(-1), np.arange(0, U * 50 + 1, 50)), shape=(U, I))
+    m.sum_duplicates()
+    excl = S.evaluation._csr_to_device(m, device)
+    users = torch.arange(U, device=device)
+    with torch.no_grad():
+        dt, avg_ms = _time_scorer(S, u16, i16, k, users, excl, 0, 1, reps, warm)
+    return {'workload': 'BASELINE configs[4], one of eight item shards: 100k users x 25k items x 256 fp16, 50 exclusions per user, top-20',
+            'value': round(U * I / dt, 1), 'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3),
+            'roofline': scoring_roofline(U, I, D, k, avg_ms)}
 
 
 def host_cores():
@@ -412,23 +520,30 @@ C1_MODEL = {'shared_common_dim': 64, 'user': {'feature_name': 'user_embedding', 
                      'regularization_weight': 1e-3, 'normalize_single_branch_input': True}}
 
 
+C1_TRAIN_STEPS = 300      # recorded batches both sides train on before the evaluation that is compared
+
+
 def bench_c1(S, device, steps):
-    """ML-1M-shaped synthetic data (U 5,816, I 3,299, 651k interactions, 18 genre tags + 768-d text, C = D = 64,
-    pairwise InfoNCE, BPR, AdamW) — BASELINE.md section 3: GPU interactions/s at the reference's batch 256 and at 4096, the CPU
-    port (oracle restatement: same torch-CPU ops, same per-row numpy sampling calls as the reference) for >= 50 timed steps of
-    batch 256 on the same inputs and parameters, one full evaluation pass on both (scores/s, NDCG@10), cores stated."""
+    """ML-1M-shaped synthetic data (U 5,816, I 3,299, 651k interactions drawn with Zipf(1) item popularity, 18 genre
+    tags + 768-d text, C = D = 64, pairwise InfoNCE, BPR, AdamW) — BASELINE.md section 3: GPU interactions/s at the reference's batch
+    256 and at 4096; the CPU port (oracle restatement: same torch-CPU ops, same per-row numpy sampling calls as the reference) timed on
+    the same inputs and parameters, cores stated; and "NDCG@10 equal to the CPU restatement on identical inputs" on a TRAINED model:
+    both sides take the same C1_TRAIN_STEPS recorded batches and modality draws from the same initial parameters
+    (train/trainer.py:204-223), then one full evaluation pass each (eval/eval.py:205-222: scores/s, NDCG@10)."""
     from oracle import eval_ref, losses_ref, model_ref, sampling_ref, train_ref
     ds = S.SyntheticDataset(C1['n_users'], C1['n_items'], C1['nnz'], item_dense={'text': 768}, item_tags={'genres': (18, 3)}, seed=0,
-                            n_negative_samples=C1['n_neg'], negative_sampling_strategy='uniform_recbole', holdout_per_user=1)
+                            n_negative_samples=C1['n_neg'], negative_sampling_strategy='uniform_recbole', holdout_per_user=1,
+                            item_popularity=1.0)
     torch.manual_seed(42)
     np.random.seed(42)
     net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(C1_MODEL), ds).to(device)
     sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     bpr = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
                                                neg_train=ds.n_negative_samples)
-    out = {'workload': 'BASELINE configs[0] shape: synthetic ML-1M (5,816 users x 3,299 items, 651k interactions, 18 genre tags + '
-                       '768-d text, C = D = 64, hidden [64], pairwise InfoNCE, BPR, 10 negatives, AdamW 1e-3 / 1e-6), user = lookup'}
-    # ---- CPU port first (it must see the initial parameters; the GPU runs train the same net afterwards)
+    out = {'workload': 'BASELINE configs[0] shape: synthetic ML-1M (5,816 users x 3,299 items, ~650k interactions with Zipf(1) item '
+                       'popularity, 18 genre tags + 768-d text, C = D = 64, hidden [64], pairwise InfoNCE, BPR, 10 negatives, AdamW 1e-3 / '
+                       '1e-6), user = lookup'}
+    # ---- CPU port: trains C1_TRAIN_STEPS batches from the initial parameters; every batch and modality draw is recorded
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = {k: v.clone() for k, v in sd0.items()}
@@ -447,30 +562,40 @@ def bench_c1(S, device, steps):
     coo = ds.interaction_matrix
     rng = np.random.default_rng(0)
     np.random.seed(42)
-    times = []
-    for s_ in range(5 + 50):
+    times, recorded = [], []
+    for s_ in range(C1_TRAIN_STEPS):
         sel = rng.integers(0, coo.nnz, size=256)
         t0 = time.perf_counter()
         u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
-        train_ref.train_step(ref, rloss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l))
+        mods = ref.sides['item'].sample_modalities(i.shape, True)                 # the per-row rng.choice calls of utilities/utils.py:69
+        train_ref.train_step(ref, rloss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), None, mods)
         times.append(time.perf_counter() - t0)
-    cpu_step = sum(times[5:]) / 50
-    # one CPU evaluation pass on the INITIAL parameters (eval/eval.py:205-222: item representations once, user batches of 256)
+        recorded.append((u, i, l, mods))
+    cpu_step = sum(times[5:55]) / 50
+    # one CPU evaluation pass on the TRAINED parameters (eval/eval.py:205-222: item representations once, user batches of 256)
     ev = ds.eval_view()
-    sd_e = {k: v.clone() for k, v in sd0.items()}
-    ref_e = model_ref.RefSingleBranchNet(sd_e, C1_MODEL, ut, it, orders=orders)
     excl, labels = ev.exclude_data.tocsr(), ev.user_sampling_matrix.tocsr()
     t0 = time.perf_counter()
     with torch.no_grad():
-        i_repr = ref_e.item_repr(torch.arange(ds.n_items), False)
+        i_repr = ref.item_repr(torch.arange(ds.n_items), False)
         nd = []
         for lo in range(0, ds.n_users, 256):
             ub = torch.arange(lo, min(lo + 256, ds.n_users))
-            r = eval_ref.evaluate(ref_e.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray(), labels[lo:lo + 256].toarray(), ks=(10,))
+            r = eval_ref.evaluate(ref.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray(), labels[lo:lo + 256].toarray(), ks=(10,))
             nd.append(r['ndcg@10'])
     cpu_eval = time.perf_counter() - t0
     cpu_ndcg = float(torch.cat(nd).mean())
-    # ---- the same evaluation pass on the GPU (initial parameters), both scorers
+    # ---- GPU engine: the same recorded batches and draws from the same initial parameters
+    net.train()
+    gopt = S.FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=1e-6)
+    fused = S.FusedTrainStep(net, bpr, gopt)
+    order = list(net.item_embedding_module.train_modality_order)
+    lut = {m: q for q, m in enumerate(order)}
+    for u, i, l, mods in recorded:
+        pos = np.vectorize(lut.__getitem__, otypes=[np.int8])(mods).reshape(-1, mods.shape[-1])
+        fused.step(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), (None, (pos, order)))
+    fused.close()
+    torch.cuda.synchronize()
     gpu_eval = {}
     for scorer in ('fp32', 'fp16_fused'):
         for rep in range(2):                                 # second pass: resident CSRs, warm kernels
@@ -480,7 +605,11 @@ def bench_c1(S, device, steps):
             m = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': ev, 'batch_size': 256})(), evaluator, device, scorer=scorer)
             torch.cuda.synchronize()
             gpu_eval[scorer] = (time.perf_counter() - t0, m['ndcg@10'])
-    # ---- GPU training throughput
+    rel = abs(gpu_eval['fp32'][1] - cpu_ndcg) / max(abs(cpu_ndcg), 1e-12)
+    within = abs(gpu_eval['fp32'][1] - cpu_ndcg) <= 0.01 * abs(cpu_ndcg) + 1e-4
+    if rel > 0.05 and abs(gpu_eval['fp32'][1] - cpu_ndcg) > 5e-4:
+        raise RuntimeError(f'c1: NDCG@10 after {C1_TRAIN_STEPS} identical steps: CPU port {cpu_ndcg:.6f}, GPU engine {gpu_eval["fp32"][1]:.6f}')
+    # ---- GPU training throughput (the trained net keeps training)
     gpu = {}
     for B in (256, 4096):
         n_steps = max(steps, 50)
@@ -496,6 +625,11 @@ def bench_c1(S, device, steps):
                         f'literal collate loop), same data and initial parameters'},
         'speedup_vs_cpu': {'b256': round(gpu['b256']['value'] / (256 / cpu_step), 1),
                            'b4096_vs_cpu_b256': round(gpu['b4096']['value'] / (256 / cpu_step), 1)},
+        'trained_ndcg': {'what': f'NDCG@10 (one held-out item per user, train exclusions) after the SAME {C1_TRAIN_STEPS} recorded batches '
+                                 f'(batch 256, literal collate + per-row modality draws) from the same initial parameters on both sides',
+                         'cpu_port': round(cpu_ndcg, 6), 'gpu_fp32_scorer': round(gpu_eval['fp32'][1], 6),
+                         'gpu_fp16_fused_scorer': round(gpu_eval['fp16_fused'][1], 6), 'rel_diff_fp32_vs_cpu': round(rel, 5),
+                         'within_1pct_plus_1e-4': bool(within)},
         'eval': {'scores': n_scores,
                  'cpu': {'value': round(n_scores / cpu_eval, 1), 'unit': 'scores/s', 'seconds': round(cpu_eval, 3), 'cores': cores,
                          'ndcg@10': round(cpu_ndcg, 6)},
@@ -503,8 +637,42 @@ def bench_c1(S, device, steps):
                               'seconds': round(gpu_eval['fp32'][0], 5), 'ndcg@10': round(gpu_eval['fp32'][1], 6)},
                  'gpu_fp16_fused': {'value': round(n_scores / gpu_eval['fp16_fused'][0], 1), 'unit': 'scores/s',
                                     'seconds': round(gpu_eval['fp16_fused'][0], 5), 'ndcg@10': round(gpu_eval['fp16_fused'][1], 6)},
-                 'what': 'one full evaluation pass of the INITIAL parameters: item representations, all users, train exclusions, '
+                 'what': 'one full evaluation pass of the TRAINED parameters: item representations, all users, train exclusions, '
                          'top-10, NDCG@10 (one held-out item per user)'}})
+    return out
+
+
+C3_MODEL = {'shared_common_dim': 128, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+            'item': {'features': [{'feature_name': 'interactions'}, {'feature_name': 'genres'}, {'feature_name': 'audio'}],
+                     'single_branch_hidden_layers': [512, 512, 512, 256, 256], 'preference_hidden_layers': [],
+                     'common_modality_dim': 512, 'embedding_regularization_type': 'pairwise_single',
+                     'regularization_temperature': 0.1, 'regularization_weight': 1e-4}}
+
+
+def bench_c3(S, device, steps):
+    """BASELINE configs[2] (Onion18 shape, conf/single/algorithms/sbnet_onion18_huge_no-user_conf.yml:39-54) on one GPU: 5,192 users x
+    13,610 items, CSR interactions + 853-tag bag + 1024-d audio, C = 512, hidden [512, 512, 512, 256, 256], D = 128, two modalities per
+    slot with pairwise InfoNCE, BPR, AdamW — interactions/s at the reference's batch 256 and at 4096, with the roofline of the
+    dominant GEMM at 4096."""
+    ds = S.SyntheticDataset(5192, 13610, 326_000, item_dense={'audio': 1024}, item_tags={'genres': (853, 5)}, seed=0,
+                            n_negative_samples=10, negative_sampling_strategy='uniform_recbole')
+    torch.manual_seed(42)
+    np.random.seed(42)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(C3_MODEL), ds).to(device)
+    bpr = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=10)
+    out = {'workload': 'BASELINE configs[2] shape: Onion18 (5,192 x 13,610, interactions CSR + 853 tags + audio 1024-d, C = 512, hidden '
+                       '[512, 512, 512, 256, 256], D = 128, k = 2 pairwise InfoNCE, BPR), user = lookup, 1 GPU'}
+    n_steps = max(min(steps, 60), 30)
+    for B in (256, 4096):
+        dt, timings = bench_training(S, ds, net, device, B, n_steps, 5, 0, 1, time_kernels=(B == 4096), loss=bpr)
+        out[f'b{B}'] = {'value': round(B * n_steps / dt, 1), 'unit': 'interactions/s', 'ms_per_step': round(dt / n_steps * 1e3, 3), 'steps': n_steps}
+        if B == 4096 and timings:
+            roof = dominant_gemm(timings, n_steps, None)
+            if roof:
+                roof['all_gemms'] = gemm_table(timings, n_steps)[:12]
+                gemm_ms = sum(r['ms_per_step'] for r in gemm_table(timings, n_steps))
+                roof['gemm_ms_per_step'] = round(gemm_ms, 4)
+                out['roofline'] = roof
     return out
 
 
@@ -579,6 +747,7 @@ def main():
     ap.add_argument('--no-scoring', action='store_true')
     ap.add_argument('--no-b256', action='store_true')
     ap.add_argument('--no-c1', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the c3 and c5-shard objects')
     ap.add_argument('--small', action='store_true', help='1/10-size workload (debug only; never a reportable number)')
     args = ap.parse_args()
 
@@ -666,7 +835,8 @@ def main():
             out['config']['replica_param_checksum_spread'] = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
             out['config']['param_checksum'] = [float(c) for c in chk]
             out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
-    roof = dominant_gemm(timings, args.steps, args.batch_size) if rank == 0 else None
+    n_params = sum(p.numel() for p in net.parameters())
+    roof = step_roofline(timings, args.steps, args.batch_size, n_params) if rank == 0 else None
     if roof:
         out['roofline'] = roof
     if not args.no_b256:
@@ -683,8 +853,11 @@ def main():
         if 'scoring' in out:
             out['scoring']['cpu_baseline'] = cpu_scoring_sample(S, ds, net)
             out['scoring']['cpu_baseline']['speedup_vs_cpu'] = round(out['scoring']['value'] / out['scoring']['cpu_baseline']['value'], 1)
-    if rank == 0 and world == 1 and not args.no_c1 and not args.small:
+    if rank == 0 and world == 1 and not args.no_configs and not args.small:
         del ds, net
+        out['c5_shard'] = bench_c5_shard(S, device)
+        out['c3'] = bench_c3(S, device, args.steps)
+    if rank == 0 and world == 1 and not args.no_c1 and not args.small:
         out['c1'] = bench_c1(S, device, args.steps)
     if rank == 0:
         print(json.dumps(out))

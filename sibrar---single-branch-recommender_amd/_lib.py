@@ -80,6 +80,7 @@ _FN = {}
 
 _TRACE = os.environ.get('SBR_TRACE_CALLS', '0') == '1'
 CALL_LOG = None      # tests: set to a list and every entry point called through ``call`` is appended as (name, args)
+CALL_TIMER = None    # ops.KernelTimer: callable(name, thunk) -> status that brackets the launch with HIP events on its stream
 
 
 def call(name: str, *args):
@@ -97,6 +98,8 @@ def call(name: str, *args):
         print(f'[sbr] {name} {args}', file=sys.stderr, flush=True)
         rc = fn(*args)
         torch.cuda.synchronize()
+    elif CALL_TIMER is not None:
+        rc = CALL_TIMER(name, lambda: fn(*args))
     else:
         rc = fn(*args)
     if rc != 0:

@@ -21,6 +21,17 @@
 //     byte cursor: the append is one buffer_store_dwordx2 + one v_add, no 64-bit address arithmetic and no key conversion
 //     (keys are built at compaction);
 //   * thresholds are compared as floats on raw accumulators, ordering / tie rules unchanged (score desc, item index asc).
+//
+// Round 3: thresholds without compactions. A user's candidate buffers are large (S5_CAPH entries per lane half, in the workspace) and
+// are not compacted during the stream; instead every lane keeps the running MAXIMUM of what it appended per accumulator register
+// ("class": 16 per lane, 32 per user, updated by one v_max inside the branch-free append, under its EXEC mask — so excluded scores
+// and scores below the threshold never enter). The k-th largest of a user's 32 class maxima is the score of a real, already
+// buffered item with k - 1 buffered items of other classes at or above it: every later item (larger index) needs a strictly larger
+// score to reach the top k. All 32 users of a wave refresh their threshold from it at once, lane-parallel (sort 16 registers by a
+// Batcher network, exchange with the partner lane, bitonic half-merge: ~270 vector instructions, no ballots, no memory), every few
+// tiles at first and every 32 tiles later. The cooperative per-user selection (s5_select: 32 ballot rounds for ONE user) remains
+// only as the overflow path of a (user, half) buffer, and the final selection + ranking runs in a kernel of its own
+// (score_topk_finalize_kernel: one wave per user, all CUs busy) instead of serially per user at the tail of the scorer's waves.
 #include "score_topk_common.h"
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -45,55 +56,86 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define S5_EVABL 0                        // lab (timing only, wrong results): 1 = the event window is never refilled
 #endif
 #define S5_EV_NONE 0xFFFFFFFFu            // padding event: its tile field matches no tile
-#define S5_CAPH 64                       // candidate entries per (user, lane half)
+#ifndef S5_CAPH
+#define S5_CAPH 256                      // candidate entries per (user, lane half); multiple of 64
+#endif
+#define S5_EH (S5_CAPH / 64)             // entries of one buffer half per lane when a wave holds a whole user's buffers
+#ifndef S5_RF
+#define S5_RF 32                         // tiles between two threshold refreshes in the steady state
+#endif
 
-// All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves are stored back (raw, unsorted), k - k / 2 to
-// b0 and k / 2 to b1 (both halves keep room: a compaction is due when ONE half passes the limit);
-// returns the k-th best score (-inf, nothing moved, while fewer than k entries exist). e: the lane's two entries as composite
-// keys (ordered score key << 32 | ~item), keep: whether they survived.
-__device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane,
-                                           unsigned long long e[2], bool keep[2]) {
+// All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves (each <= S5_CAPH: lane l holds entries l, l + 64,
+// ... of both) are found by a bitwise binary search for the k-th largest score key over ballot counts (ties at that key: smallest
+// item indices stay). COMPACT: the survivors are stored back raw, unsorted — k - k / 2 to b0[0 ..) and k / 2 to b1[0 ..) (overflow
+// path of the scorer: both halves keep room) — else all of them to b0[0 .. k) (finalize kernel). Fewer than k entries: with COMPACT
+// nothing moves and -inf is returned; without, all n0 + n1 entries are gathered into b0[0 .. n0 + n1). Returns the k-th best score.
+template <bool SPLIT>
+__device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane) {
   const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
   // written and read by this wave only: same-CU vector memory path, in order
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  const unsigned long long r0 = lane < n0 ? b0[lane] : 0ull, r1 = lane < n1 ? b1[lane] : 0ull;
-  e[0] = lane < n0 ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(r0 >> 32))) << 32) | (r0 & 0xFFFFFFFFull)) : 0ull;
-  e[1] = lane < n1 ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(r1 >> 32))) << 32) | (r1 & 0xFFFFFFFFull)) : 0ull;
-  keep[0] = lane < n0;
-  keep[1] = lane < n1;
-  if (n0 + n1 < k) return -INFINITY;
-  const unsigned int h0 = (unsigned int)(e[0] >> 32), h1 = (unsigned int)(e[1] >> 32);
-  // bitwise binary search for the k-th largest score key over ballot counts. It stops as soon as EXACTLY k entries lie at or above
-  // the prefix found so far: they are the k best, and the prefix itself is a valid (slightly low) threshold — with keys spread over
-  // the fp32 range that happens after 10-14 of the 32 steps (ties across the k-th place never stop it early: the count jumps past k,
-  // and the item-index search below resolves them as before).
+  unsigned long long raw[2 * S5_EH], e[2 * S5_EH];
+#pragma unroll
+  for (int j = 0; j < S5_EH; ++j) {
+    raw[j] = lane + 64 * j < n0 ? b0[lane + 64 * j] : 0ull;
+    raw[S5_EH + j] = lane + 64 * j < n1 ? b1[lane + 64 * j] : 0ull;
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * S5_EH; ++j) {
+    const bool have = lane + 64 * (j % S5_EH) < (j < S5_EH ? n0 : n1);
+    e[j] = have ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw[j] >> 32))) << 32) | (raw[j] & 0xFFFFFFFFull)) : 0ull;
+  }
+  const int c0 = (n0 + 63) >> 6, c1 = (n1 + 63) >> 6;        // occupied 64-entry chunks per half (wave-uniform)
+  auto count_ge = [&](unsigned long long C) {
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < S5_EH; ++j) {
+      if (j < c0) cnt += __popcll(__ballot(e[j] >= C));
+      if (j < c1) cnt += __popcll(__ballot(e[S5_EH + j] >= C));
+    }
+    return cnt;
+  };
+  if (n0 + n1 < k) {
+    if constexpr (SPLIT) return -INFINITY;
+    // gather: half 1's entries behind half 0's (n0 + n1 < k <= 32 <= 64: one chunk each)
+    if (lane < n1) b0[n0 + lane] = raw[S5_EH];
+    return -INFINITY;
+  }
+  // k-th largest composite key (score key << 32 | ~item): composites are unique, so exactly k entries lie at or above it. The
+  // search runs on the high word first (32 steps at most; it stops as soon as EXACTLY k entries lie at or above the prefix found
+  // so far) and on the low word only when several entries share the k-th score key.
   unsigned int T = 0u;
   int c_ge = n0 + n1;
   for (int bit = 31; bit >= 0; --bit) {
     const unsigned int trial = T | (1u << bit);
-    const int cnt = __popcll(__ballot(h0 >= trial)) + __popcll(__ballot(h1 >= trial));
+    const int cnt = count_ge((unsigned long long)trial << 32);
     if (cnt >= k) { T = trial; c_ge = cnt; if (cnt == k) break; }
   }
   unsigned long long C = (unsigned long long)T << 32;
   if (c_ge != k) {                                           // several entries share the k-th key: smallest item indices stay
-    const int need = k - (__popcll(__ballot(h0 > T)) + __popcll(__ballot(h1 > T)));
-    const unsigned int l0 = (unsigned int)e[0], l1 = (unsigned int)e[1];
     unsigned int Lw = 0u;
     for (int bit = 31; bit >= 0; --bit) {
       const unsigned int trial = Lw | (1u << bit);
-      const int cnt = __popcll(__ballot(h0 == T && l0 >= trial)) + __popcll(__ballot(h1 == T && l1 >= trial));
-      Lw = cnt >= need ? trial : Lw;
+      // entries with a larger score key count as well: (T + 1) << 32 > any (T, low) composite
+      const int cnt = count_ge(((unsigned long long)T << 32) | trial);
+      Lw = cnt >= k ? trial : Lw;
     }
     C |= (unsigned long long)Lw;
   }
-  keep[0] = e[0] >= C;
-  keep[1] = e[1] >= C;
-  const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
-  const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m0, 0u));
-  const int p1 = __popcll(m0) + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m1, 0u));
-  const int kh = k - (k >> 1);                               // survivors 0 .. kh - 1 stay in half 0, the rest go to half 1
-  if (keep[0]) (p0 < kh ? b0 + p0 : b1 + (p0 - kh))[0] = r0;
-  if (keep[1]) (p1 < kh ? b0 + p1 : b1 + (p1 - kh))[0] = r1;
+  // survivors to their places, in (chunk, lane) order
+  const int kh = SPLIT ? k - (k >> 1) : k;                   // survivors 0 .. kh - 1 go to b0, the rest to b1
+  int before = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * S5_EH; ++j) {
+    const bool live = (j < S5_EH) ? (j < c0) : (j - S5_EH < c1);
+    if (live) {
+      const bool keep = e[j] >= C;
+      const unsigned long long m = __ballot(keep);
+      const int p = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+      if (keep) (p < kh ? b0 + p : b1 + (p - kh))[0] = raw[j];
+      before += __popcll(m);
+    }
+  }
   // T may be a PREFIX of the k-th key (low bits clear): as a float that is a value at or below the k-th best score — a valid
   // threshold — except that clearing into the exponent of a negative score can produce a NaN pattern: no bound then
   const float t = st_key2f(T);
@@ -138,7 +180,7 @@ __device__ __forceinline__ float s5_max2(float a, float b) {
 // the wave's candidate block (s5_block_rsrc).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <unsigned int BIT, int C>
-__device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs) {
+__device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs, float& cmax) {
   unsigned int tmp;
   asm volatile(
       "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
@@ -148,10 +190,66 @@ __device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int e
       "buffer_store_dword %[tmp], %[pos], %[rs], 0 offen\n\t"
       "buffer_store_dword %[a], %[pos], %[rs], 0 offen offset:4\n\t"
       "v_add_u32_e32 %[pos], 8, %[pos]\n\t"
+      "v_max_f32_e32 %[cm], %[cm], %[a]\n\t"               /* class maximum of what was appended (same EXEC mask) */
       "s_mov_b64 exec, -1"
-      : [pos] "+v"(pos), [tmp] "=&v"(tmp)
+      : [pos] "+v"(pos), [tmp] "=&v"(tmp), [cm] "+v"(cmax)
       : [a] "v"(a), [thr] "v"(thr), [ex] "v"(ex), [il] "v"(il), [rs] "s"(rs), [bit] "n"(BIT), [c] "n"(C)
       : "vcc", "memory");
+}
+__device__ __forceinline__ float s5_min2(float a, float b) {
+  float m;
+  asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
+// Batcher's odd-even merge sort of 16 values (63 compare-exchanges), descending, on registers: every index is a compile-time
+// constant after unrolling. All lanes sort their own 16 values at once.
+struct S5Ce { unsigned char i, j; };
+__device__ static constexpr S5Ce S5_SORT16[63] = {
+    {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {10, 11}, {12, 13}, {14, 15},
+    {0, 2}, {1, 3}, {4, 6}, {5, 7}, {8, 10}, {9, 11}, {12, 14}, {13, 15},
+    {1, 2}, {5, 6}, {9, 10}, {13, 14},
+    {0, 4}, {1, 5}, {2, 6}, {3, 7}, {8, 12}, {9, 13}, {10, 14}, {11, 15},
+    {2, 4}, {3, 5}, {10, 12}, {11, 13},
+    {1, 2}, {3, 4}, {5, 6}, {9, 10}, {11, 12}, {13, 14},
+    {0, 8}, {1, 9}, {2, 10}, {3, 11}, {4, 12}, {5, 13}, {6, 14}, {7, 15},
+    {4, 8}, {5, 9}, {6, 10}, {7, 11},
+    {2, 4}, {3, 5}, {6, 8}, {7, 9}, {10, 12}, {11, 13},
+    {1, 2}, {3, 4}, {5, 6}, {7, 8}, {9, 10}, {11, 12}, {13, 14}};
+// k-th largest (1 <= k <= 32, wave-uniform) of the 32 values a user holds in its two lanes l and l ^ 32 (16 each): every lane pair
+// for its own user, all 32 users of the wave at once. -inf entries are ordinary values (fewer than k real ones -> -inf).
+__device__ __forceinline__ float s5_kth_of_32(const float (&cm)[16], int k) {
+  float a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = cm[r];
+#pragma unroll
+  for (int c = 0; c < 63; ++c) {
+    const int i = S5_SORT16[c].i, j = S5_SORT16[c].j;
+    const float hi = s5_max2(a[i], a[j]), lo = s5_min2(a[i], a[j]);
+    a[i] = hi; a[j] = lo;                                    // descending: a[0] the largest
+  }
+  // the partner's sorted list, reversed: max(a[i], b[15 - i]) are the 16 largest of the 32 (a bitonic sequence), min(...) the rest
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float b = __shfl_xor(a[15 - i], 32, 64);
+    v[i] = k <= 16 ? s5_max2(a[i], b) : s5_min2(a[i], b);
+  }
+  // bitonic merge, descending
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if ((i & d) == 0) {
+        const float hi = s5_max2(v[i], v[i + d]), lo = s5_min2(v[i], v[i + d]);
+        v[i] = hi; v[i + d] = lo;
+      }
+    }
+  }
+  const int e = (k - 1) & 15;
+  float t = v[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t = e == i ? v[i] : t;
+  return t;
 }
 // raw buffer descriptor of a wave's candidate block: base, stride 0, 32 users x 2 halves x S5_CAPH entries of 8 bytes, gfx950 format word
 __device__ __forceinline__ i32x4 s5_block_rsrc(const void* block) {

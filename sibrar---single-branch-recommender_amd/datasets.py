@@ -24,14 +24,21 @@ from .sampling import (DevicePositiveIndex, PositiveIndex, dataset_sampler_colla
                        recbole_negative_collate, uniform_negative_collate)
 
 
-def synthetic_interactions(n_users: int, n_items: int, nnz: int, seed: int = 0) -> sp.csr_matrix:
-    """Per-user degree from a log-normal scaled to the target density, items uniform without replacement per user."""
+def synthetic_interactions(n_users: int, n_items: int, nnz: int, seed: int = 0, item_popularity: float = 0.0) -> sp.csr_matrix:
+    """Per-user degree from a log-normal scaled to the target density; items uniform, or — ``item_popularity`` = a > 0 — drawn with
+    probability proportional to 1 / rank^a over a random ranking of the items ("Zipf 1.0 for popularity realism":
+    something a model can learn, so that a trained model's NDCG is above the noise floor)."""
     rng = np.random.default_rng(seed)
     deg = rng.lognormal(mean=0., sigma=1., size=n_users)
     deg = np.maximum(1, np.round(deg / deg.sum() * nnz)).astype(np.int64)
     deg = np.minimum(deg, max(1, n_items // 2))
     rows = np.repeat(np.arange(n_users, dtype=np.int64), deg)
-    cols = rng.integers(0, n_items, size=rows.size)
+    if item_popularity > 0:
+        p = 1.0 / np.arange(1, n_items + 1, dtype=np.float64) ** float(item_popularity)
+        ranking = np.random.default_rng(seed + 11).permutation(n_items)
+        cols = ranking[np.searchsorted(np.cumsum(p / p.sum()), rng.random(rows.size), side='right').clip(max=n_items - 1)]
+    else:
+        cols = rng.integers(0, n_items, size=rows.size)
     m = sp.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(n_users, n_items))
     m.sum_duplicates()
     m.data[:] = 1
@@ -43,9 +50,9 @@ class SyntheticDataset:
     def __init__(self, n_users: int, n_items: int, nnz: int, item_dense: Dict[str, int] = None,
                  item_tags: Dict[str, tuple] = None, user_categorical: Dict[str, int] = None, seed: int = 0,
                  n_negative_samples: int = 10, negative_sampling_strategy: str = 'uniform_recbole',
-                 holdout_per_user: int = 0):
+                 holdout_per_user: int = 0, item_popularity: float = 0.0):
         self.n_users, self.n_items = n_users, n_items
-        inter = synthetic_interactions(n_users, n_items, nnz, seed)
+        inter = synthetic_interactions(n_users, n_items, nnz, seed, item_popularity)
         self.holdout = None
         if holdout_per_user > 0:
             # last `holdout_per_user` items of each user (>= 2 interactions) become the evaluation labels

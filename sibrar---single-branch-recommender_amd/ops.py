@@ -43,13 +43,28 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 class KernelTimer:
     """Optional HIP-event timing of individual kernel launches on the stream they are launched on (torch's current stream is
-    the stream handed to the C ABI). bench.py enables it over the timed region to measure the dominant kernel live."""
+    the stream handed to the C ABI). bench.py enables it over plain-launch steps to measure every kernel of the step live:
+    ``('call', entry point)`` for every C-ABI call, and the GEMM / scorer wrappers add a key that carries the shape."""
     enabled = False
     records = {}          # key -> [(start_event, stop_event)]
 
     @classmethod
     def reset(cls, enabled: bool):
+        from . import _lib
         cls.enabled, cls.records = enabled, {}
+        _lib.CALL_TIMER = cls._bracket if enabled else None
+
+    @classmethod
+    def _bracket(cls, name, thunk):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = thunk()
+        b.record()
+        cls.records.setdefault(('call', name), []).append((a, b))
+        key = getattr(_TIMED_KEY, 'value', None)
+        if key is not None:              # the shape-carrying key of the wrapper that made this call: the same event pair
+            cls.records.setdefault(key, []).append((a, b))
+        return rc
 
     @classmethod
     def results(cls):
@@ -57,15 +72,20 @@ class KernelTimer:
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in cls.records.items()}
 
 
+import threading as _threading
+
+_TIMED_KEY = _threading.local()
+
+
 def _timed(key, fn):
+    """``fn`` makes ONE C-ABI call; while KernelTimer is on, the events around that call are also filed under ``key``."""
     if not KernelTimer.enabled:
         return fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    out = fn()
-    b.record()
-    KernelTimer.records.setdefault(key, []).append((a, b))
-    return out
+    _TIMED_KEY.value = key
+    try:
+        return fn()
+    finally:
+        _TIMED_KEY.value = None
 
 
 # ---- raw kernel helpers (no autograd) -------------------------------------------------------------------------------

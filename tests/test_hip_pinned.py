@@ -420,8 +420,8 @@ def test_c3_step_at_full_shapes_against_the_cpu_oracle():
 
 def test_c2_step_at_the_bench_batch_against_the_cpu_oracle():
     """BASELINE configs[1] exactly as ``bench.py`` times it: the bench's model (bench.build), one loader batch of 8,192 interactions
-    x 11 slots with its recorded modality draw, ``FusedTrainStep.step`` three times — plain launches, hipGraph capture + replay,
-    replay — with the optimizer launch replaced by a recorder, against the CPU oracle (oracle/model_ref.py restating
+    x 11 slots with its recorded modality draw, ``FusedTrainStep.step`` five times — three passes of plain launches (the arena is sized, grown,
+    re-sighted), hipGraph capture + replay, replay — with the optimizer launch replaced by a recorder, against the CPU oracle (oracle/model_ref.py restating
     train/trainer.py:204-223 -> sgd_alg.py:2116-2125, rec_losses.py:88-113) on the same parameters, batch and draw: the
     sampled-softmax loss (1e-4 relative) and EVERY gradient incl. both embedding tables (norm-wise 1e-4). The call log of the
     plain-launch pass must show the launch mix the bench line is timed on: bf16-split projector, bf16-split K = N = 128 products
@@ -455,14 +455,15 @@ def test_c2_step_at_the_bench_batch_against_the_cpu_oracle():
     assert tuple(i.shape) == (8192, 11)
     draws = fused.draw(u.shape, i.shape)
     recs = []
-    for rep in range(3):
+    n_rep = 5            # plain launches: sizing the arena, growing it, first sighting in the grown arena; then capture + replay, replay
+    for rep in range(n_rep):
         if rep == 0:
             _lib.CALL_LOG = []
         total, rec, reg = fused.step(u, i, labels, draws)
         if rep == 0:
             log, _lib.CALL_LOG = _lib.CALL_LOG, None
         recs.append(rec.cpu())
-    assert fused.n_replays == 2
+    assert fused.n_replays == 2 and len(seen) == n_rep
     # ---- the launch mix of the timed path
     names = [n_ for n_, _ in log]
     lib = _lib.lib()
@@ -490,7 +491,7 @@ def test_c2_step_at_the_bench_batch_against_the_cpu_oracle():
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     assert {'user_embedding_module.embedding_layer.weight'} <= set(grads) and len(grads) == len(seen[0])
     sc = gscale(grads.values())
-    for rep in range(3):
+    for rep in range(n_rep):
         close(recs[rep], rl.detach().double(), what=f'rec loss (pass {rep})', rtol=1e-4, atol=1e-7)
         for k_, g in grads.items():
             close(seen[rep][k_].cpu(), g, what=f'grad {k_} (pass {rep})', rtol=2e-4, atol=1e-7, scale=sc, norm_rtol=1e-4)

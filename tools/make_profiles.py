@@ -62,6 +62,12 @@ if fetch or write:
     with open(os.path.join(out, f'{tag}_bench_hbm_traffic.csv'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/profile_round.sh) -- python3 bench.py '
                 '--steps 50 --warmup 5 --no-cpu-baseline --no-b256 --no-c1\n')
+        import hashlib, glob
+        h = hashlib.sha256()
+        for p_ in sorted(glob.glob(os.path.join(root, 'sibrar---single-branch-recommender_amd', 'csrc', '*.h*'))):
+            h.update(os.path.basename(p_).encode())
+            h.update(open(p_, 'rb').read())
+        f.write(f'# csrc_sha16={h.hexdigest()[:16]} (bench.py csrc_sha16(): the kernel sources these counters were collected with)\n')
         f.write('# counters are KiB per dispatch; corrected_MB = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / 1e6 '
                 '(gfx950: FETCH_SIZE tallies 128-byte requests of wide coalesced reads at 64 bytes)\n')
         f.write('kernel,grid_threads,launches,mean_FETCH_SIZE_KiB_raw,mean_WRITE_SIZE_KiB,corrected_HBM_MB_per_launch\n')

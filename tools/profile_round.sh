@@ -8,7 +8,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
-ARGS="bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-b256 --no-c1"
+ARGS="bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-b256 --no-c1 --no-configs"
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $ARGS > $O/stats.log 2>&1
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python3 $ARGS > $O/fetch.log 2>&1
