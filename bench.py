@@ -372,16 +372,20 @@ def step_roofline(timings, steps, batch, n_params):
 
 
 def _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm):
+    """-> (seconds per pass, avg ms of the call's launches with the exclusion mask resident in the scorer's layout, avg ms of a call
+    that also converts the exclusion CSR into that layout). The mask of an evaluation split is constant (eval/eval.py:219), the
+    product converts it once per split (evaluation.py); the timed passes therefore start with it resident, like the CSR itself."""
     import torch.distributed as dist
+    holder = S.ops.ScorerExclusions()
     for _ in range(warm):                                # the chip's clock settles over the first few passes of a burst
-        S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+        S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo, exclusions=holder)
     S.ops.KernelTimer.reset(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+        val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo, exclusions=holder)
         if world > 1:
             val, idx = S.parallel.all_gather_topk(val, idx, k)
     torch.cuda.synchronize()
@@ -389,13 +393,17 @@ def _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm):
         dist.barrier()
     dt = (time.perf_counter() - t0) / reps
     res = S.ops.KernelTimer.results()
-    S.ops.KernelTimer.reset(False)
     ts = [t for key, v in res.items() if key[0] == 'score_topk_f16' for t in v]
+    S.ops.KernelTimer.reset(True)
+    for _ in range(max(reps // 4, 2)):                   # the same call when it also builds the event stream from the CSR
+        S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo)
+    tb = [t for key, v in S.ops.KernelTimer.results().items() if key[0] == 'score_topk_f16' for t in v]
+    S.ops.KernelTimer.reset(False)
     if world > 1:
         t = torch.tensor([dt], device=u16.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    return dt, sum(ts) / len(ts)
+    return dt, sum(ts) / len(ts), sum(tb) / len(tb)
 
 
 def scoring_roofline(n_users, n_items, D, k, avg_ms, traffic=None, traffic_source=None, kernel=None):
@@ -404,7 +412,7 @@ def scoring_roofline(n_users, n_items, D, k, avg_ms, traffic=None, traffic_sourc
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_MFMA_F16, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_MFMA_F16, 4),
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes': (n_users + n_items) * D * 2 + n_users * k * 8,
-            'kernel': kernel or 'fused fp16 scorer: sbr_score_topk_f16 (every launch of the call)', 'avg_launch_ms': round(avg_ms, 4)}
+            'kernel': kernel or 'fused fp16 scorer: sbr_score_topk_f16 (score_topk_f16_n_kernel + score_topk_finalize_kernel; exclusion mask resident as event stream)', 'avg_launch_ms': round(avg_ms, 4)}
 
 
 def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):
@@ -417,11 +425,13 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):
         users = torch.arange(ds.n_users, device=device)
         u16 = S.ops.cast_f16(net.get_user_representations(users))
         excl = S.evaluation._csr_to_device(ds.user_sampling_matrix_train, device)
-        dt, avg_ms = _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm)
+        dt, avg_ms, build_ms = _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm)
     tr, src = pmc_scorer_traffic(ds.n_users) if world == 1 else (None, None)
     return {'metric': 'full-catalogue scores/s (fused fp16 score+mask+top-20)', 'value': ds.n_users * ds.n_items / dt,
             'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
             'sharding': f'items/{world}', 'exclusions': int(excl[1].numel()),
+            'exclusion_mask': 'resident in the scorer\'s layout (built once per split by the first evaluation; a call that also converts '
+                              f'the CSR takes {build_ms:.3f} ms)', 'ms_per_call_with_mask_conversion': round(build_ms, 4),
             'roofline': scoring_roofline(ds.n_users, hi - lo, int(i16.shape[1]), k, avg_ms, tr, src)}
 
 
@@ -440,9 +450,10 @@ def bench_c5_shard(S, device, k=20, reps=12, warm=6):
     excl = S.evaluation._csr_to_device(m, device)
     users = torch.arange(U, device=device)
     with torch.no_grad():
-        dt, avg_ms = _time_scorer(S, u16, i16, k, users, excl, 0, 1, reps, warm)
+        dt, avg_ms, build_ms = _time_scorer(S, u16, i16, k, users, excl, 0, 1, reps, warm)
     return {'workload': 'BASELINE configs[4], one of eight item shards: 100k users x 25k items x 256 fp16, 50 exclusions per user, top-20',
             'value': round(U * I / dt, 1), 'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3),
+            'ms_per_call_with_mask_conversion': round(build_ms, 4),
             'roofline': scoring_roofline(U, I, D, k, avg_ms)}
 
 

@@ -380,15 +380,20 @@ int sbr_rank_metrics(const int* topk_idx, int kmax, const long* u_idx, const lon
 /* fused scorer: fp16 MFMA  U[Bu, D] x I[I_s, D]^T  with the exclusion mask and the running per-user top-k kept on chip; the
  * [Bu, I_s] score matrix is never written (BASELINE config 5). D in {64, 128, 256}, k <= 32. Output sorted by (score desc, item
  * index asc); indices are global (item_offset + column). u_idx: exclusion-CSR row of every scored row (NULL: identity).
- * excl_nnz: number of entries of `excl_indices` (an upper bound of the exclusions of the scored rows; sizes the event stream the
- * call builds from the CSR rows, see csrc/score_topk_f16_n.hip). ABI 2: excl_nnz is new. */
+ * excl_nnz: number of entries of `excl_indices` (an upper bound of the exclusions of the scored rows).
+ * Exclusions reach the kernel as an EVENT STREAM built from the CSR rows (csrc/score_topk_f16_n.hip) in the caller-owned buffer
+ * `events` (sbr_score_topk_f16_events_bytes(Bu, excl_nnz) bytes; NULL without exclusions): build_events != 0 builds it first (three
+ * small launches), 0 means the buffer holds the stream an earlier call with the same (u_idx, CSR, item_offset, I, D) built — the
+ * exclusion mask of an evaluation split (eval/eval.py:219: dataset.exclude_data) is the same for every evaluation of the split.
+ * ABI 3: events / events_bytes / build_events are new, the workspace no longer holds the event stream. */
 int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
                        const long* excl_indptr, const int* excl_indices, long excl_nnz, int item_offset, int k, float* out_val,
-                       int* out_idx, void* workspace, long workspace_bytes, void* stream);
-/* bytes of `workspace` for the call above: per-user candidate buffers (1 KB per user, L2-resident scratch touched only by the wave
- * that owns the user; contents need no initialisation) + the exclusion event stream of the call (4 bytes per CSR entry + per-user
- * bookkeeping; excl_nnz = 0 when no exclusion CSR is passed). */
-long sbr_score_topk_f16_workspace(long Bu, int I, int k, long excl_nnz);
+                       int* out_idx, void* workspace, long workspace_bytes, void* events, long events_bytes, int build_events,
+                       void* stream);
+/* bytes of `workspace` for the call above: per-user candidate buffers (4 KB per user: scratch written by the wave that owns the user
+ * and read by the final-selection launch of the same call; contents need no initialisation) + their fill counts. */
+long sbr_score_topk_f16_workspace(long Bu, int I, int k);
+long sbr_score_topk_f16_events_bytes(long Bu, long excl_nnz);
 /* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
 int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);
 

@@ -11,6 +11,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libsibrar_hip.so')
+if os.environ.get('SBR_LAB_LIB'):        # lab: a kernel variant built by tools/lab/build_*_variants.sh (never set in product runs)
+    LIB_PATH = os.path.abspath(os.environ['SBR_LAB_LIB'])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'sibrar_hip.h')
 
 

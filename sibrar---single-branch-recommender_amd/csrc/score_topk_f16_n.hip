@@ -60,6 +60,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define S5_CAPH 256                      // candidate entries per (user, lane half); multiple of 64
 #endif
 #define S5_EH (S5_CAPH / 64)             // entries of one buffer half per lane when a wave holds a whole user's buffers
+#ifndef S5_PRE_TILES
+#define S5_PRE_TILES 16                  // tiles of the prefix pass (class maxima only, no appends) of catalogues of >= 96 tiles
+#endif
+#ifndef S5_EXSPLIT
+#define S5_EXSPLIT 1                     // 1: tiles without exclusion events append without testing exclusion bits (two code copies)
+#endif
 #ifndef S5_RF
 #define S5_RF 32                         // tiles between two threshold refreshes in the steady state
 #endif
@@ -179,16 +185,36 @@ __device__ __forceinline__ float s5_max2(float a, float b) {
 // sequence has no vector -> scalar hand-over and no branch; all lanes are active on entry and on exit. rs: buffer descriptor of
 // the wave's candidate block (s5_block_rsrc).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <unsigned int BIT, int C>
+#ifndef S5_NOSTORE
+#define S5_NOSTORE 0                      // lab (timing only, wrong results): the append stores nothing
+#endif
+#if S5_NOSTORE
+#define S5_STORE_ASM
+#else
+#define S5_STORE_ASM "buffer_store_dword %[tmp], %[pos], %[rs], 0 offen\n\t" "buffer_store_dword %[a], %[pos], %[rs], 0 offen offset:4\n\t"
+#endif
+template <unsigned int BIT, int C, bool EX>
 __device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs, float& cmax) {
   unsigned int tmp;
+  if constexpr (!EX) {                                       // a tile without exclusion events: no exclusion bit to test
+    asm volatile(
+        "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
+        "v_subrev_u32_e32 %[tmp], %[c], %[il]\n\t"
+        S5_STORE_ASM
+        "v_add_u32_e32 %[pos], 8, %[pos]\n\t"
+        "v_max_f32_e32 %[cm], %[cm], %[a]\n\t"
+        "s_mov_b64 exec, -1"
+        : [pos] "+v"(pos), [tmp] "=&v"(tmp), [cm] "+v"(cmax)
+        : [a] "v"(a), [thr] "v"(thr), [il] "v"(il), [rs] "s"(rs), [c] "n"(C)
+        : "vcc", "memory");
+    return;
+  }
   asm volatile(
       "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
       "v_and_b32_e32 %[tmp], %[bit], %[ex]\n\t"
       "v_cmpx_eq_u32_e32 0, %[tmp]\n\t"
       "v_subrev_u32_e32 %[tmp], %[c], %[il]\n\t"
-      "buffer_store_dword %[tmp], %[pos], %[rs], 0 offen\n\t"
-      "buffer_store_dword %[a], %[pos], %[rs], 0 offen offset:4\n\t"
+      S5_STORE_ASM
       "v_add_u32_e32 %[pos], 8, %[pos]\n\t"
       "v_max_f32_e32 %[cm], %[cm], %[a]\n\t"               /* class maximum of what was appended (same EXEC mask) */
       "s_mov_b64 exec, -1"
@@ -267,8 +293,7 @@ template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS 
 __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const unsigned int* __restrict__ events,
     const int* __restrict__ group_base, int item_offset, int k, int n_pre, int W,
-    float* __restrict__ out_val, int* __restrict__ out_idx, unsigned long long* __restrict__ gbuf,
-    unsigned long long* __restrict__ dbgbuf) {
+    int* __restrict__ cnt_out, unsigned long long* __restrict__ gbuf, unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
   constexpr int ST_TILE = 32 * NJ;
   constexpr int PF = NJ == 1 ? S5_PF1 : S5_PF2;            // fragment prefetch distance in K steps
@@ -458,10 +483,10 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
 
 
   // ---- pass 1: prefix tiles, running maximum per accumulator register (item class) ----
-  if (PRE && n_pre > 0) {
-    f32x16 cm;                                             // item class = (lane half, accumulator register): 32 per user
+  float cm[16];                                            // item class = (lane half, accumulator register): 32 per user
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+  for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+  if (PRE && n_pre > 0) {
     for (int v = 0; v < n_pre; ++v) {
       const int j0 = v * ST_TILE;
       S5_TILE_BODY(v, PF_PRE)
@@ -490,29 +515,27 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         else cm[r] = fmaxf(cm[r], acc[0][r]);
       }
     }
-    // k-th largest of the user's 32 class maxima (16 in each of its two lanes): bitwise binary search on the ordered keys,
-    // every lane pair for its own user. The threshold admits scores EQUAL to the bound (its items are not in any buffer).
+    // k-th largest of the user's 32 class maxima (16 in each of its two lanes), every lane pair for its own user. The threshold
+    // admits scores EQUAL to the bound (its items are not in any buffer: the main pass meets them again): one ulp below it.
     {
-      unsigned int T = 0u;
-      for (int bit = 31; bit >= 0; --bit) {
-        const unsigned int trial = T | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c += st_f2key(cm[r]) >= trial;
-        c += __shfl_xor(c, 32, 64);
-        T = c >= k ? trial : T;
-      }
-      // T = 0x007FFFFF is the key of -inf (fewer than k finite classes): no bound
-      thr = T > 0x007FFFFFu ? st_key2f(T - 1u) : -INFINITY;
+      const float tk = s5_kth_of_32(cm, k);
+      const unsigned int key = st_f2key(tk);
+      // key 0x007FFFFF is -inf (fewer than k finite classes): no bound
+      thr = key > 0x007FFFFFu ? st_key2f(key - 1u) : -INFINITY;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;       // the main pass keeps the class maxima of what it APPENDS
     S5_EV_RESTART()                                        // the main pass starts again from the first tile
   }
 
   // ---- pass 2: all tiles, lane-local threshold filter and appends ----
   const int pos_limit = lane_base + LIMIT * 8;
+  // threshold refresh from the class maxima: after tiles 0, 1, 2, 3, 5, 8, 12, ... (gaps growing by half) while the thresholds are
+  // still crude, every S5_RF tiles in the steady state
+  int next_rf = n_pre > 0 ? S5_RF - 1 : 0;
   for (int tl = 0; tl < n_tiles; ++tl) {
     if (__ballot(pos > pos_limit)) {
-      // ---- maintenance (cold): compact the users with a half above LIMIT so that this tile's appends cannot overflow
+      // ---- overflow (cold): a (user, half) buffer is nearly full — select that user's k best so that this tile's appends fit
       const unsigned long long tm0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
       unsigned long long need = __ballot(pos > pos_limit);
       need = (need | (need >> 32)) & 0xFFFFFFFFull;
@@ -522,11 +545,9 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         need &= need - 1ull;
         const int n0 = __builtin_amdgcn_readlane(cnt, u), n1 = __builtin_amdgcn_readlane(cnt, u + 32);
         unsigned long long* b0 = wgb + (long)u * (2 * S5_CAPH);
-        unsigned long long e[2];
-        bool kp[2];
-        const float nt = s5_select(b0, b0 + S5_CAPH, n0, n1, k, lane, e, kp);
+        const float nt = s5_select<true>(b0, b0 + S5_CAPH, n0, n1, k, lane);
         if (n0 + n1 >= k && l31 == u) {
-          thr = nt;
+          thr = nt > thr ? nt : thr;
           pos = lane_base + (half ? (k >> 1) : k - (k >> 1)) * 8;
         }
         if constexpr (DBG == 4) ++n_ins;
@@ -573,21 +594,38 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     for (int i = 0; i < 8 * NJ; ++i) any_g |= gm[i];
     if constexpr (DBG == 2) { if (any_g) asm volatile("s_nop 0"); continue; }
     if (any_g) {
-      // item of register r: nj * 32 + (r & 3) + 8 * (r >> 2) (+ 4 * half, in item_lane); exclusion bit nj * 16 + r
-#define S5_PAIR(NJI, G)                                                                                                  \
-      if (gm[(NJI) * 8 + (G)]) {                                                                                         \
-        s5_try_append<(1u << ((NJI) * 16 + 2 * (G))), (NJI) * 32 + ((2 * (G)) & 3) + 8 * ((2 * (G)) >> 2)>(acc[NJI][2 * (G)], thr, ex, pos, item_lane, wrs);             \
-        s5_try_append<(1u << ((NJI) * 16 + 2 * (G) + 1)), (NJI) * 32 + ((2 * (G) + 1) & 3) + 8 * ((2 * (G) + 1) >> 2)>(acc[NJI][2 * (G) + 1], thr, ex, pos, item_lane, wrs); \
+      // item of register r: nj * 32 + (r & 3) + 8 * (r >> 2) (+ 4 * half, in item_lane); exclusion bit nj * 16 + r. A pair that
+      // did not fire is the common case: its test falls through (the append blocks are laid out of line: a taken branch costs the
+      // wave an instruction-fetch bubble, sixteen of them per tile)
+#define S5_PAIR(NJI, G, EXF)                                                                                             \
+      if (__builtin_expect(gm[(NJI) * 8 + (G)] != 0ull, 0)) {                                                            \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G))), (NJI) * 32 + ((2 * (G)) & 3) + 8 * ((2 * (G)) >> 2), EXF>(acc[NJI][2 * (G)], thr, ex, pos, item_lane, wrs, cm[2 * (G)]);             \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G) + 1)), (NJI) * 32 + ((2 * (G) + 1) & 3) + 8 * ((2 * (G) + 1) >> 2), EXF>(acc[NJI][2 * (G) + 1], thr, ex, pos, item_lane, wrs, cm[2 * (G) + 1]); \
         if constexpr (DBG == 4) ++n_evt;                                                                                 \
       }
-      S5_PAIR(0, 0) S5_PAIR(0, 1) S5_PAIR(0, 2) S5_PAIR(0, 3) S5_PAIR(0, 4) S5_PAIR(0, 5) S5_PAIR(0, 6) S5_PAIR(0, 7)
-      if constexpr (NJ == 2) {
-        S5_PAIR(NJ - 1, 0) S5_PAIR(NJ - 1, 1) S5_PAIR(NJ - 1, 2) S5_PAIR(NJ - 1, 3) S5_PAIR(NJ - 1, 4) S5_PAIR(NJ - 1, 5) S5_PAIR(NJ - 1, 6) S5_PAIR(NJ - 1, 7)
+#define S5_PAIRS(EXF)                                                                                                    \
+      S5_PAIR(0, 0, EXF) S5_PAIR(0, 1, EXF) S5_PAIR(0, 2, EXF) S5_PAIR(0, 3, EXF) S5_PAIR(0, 4, EXF) S5_PAIR(0, 5, EXF) S5_PAIR(0, 6, EXF) S5_PAIR(0, 7, EXF) \
+      if constexpr (NJ == 2) {                                                                                           \
+        S5_PAIR(NJ - 1, 0, EXF) S5_PAIR(NJ - 1, 1, EXF) S5_PAIR(NJ - 1, 2, EXF) S5_PAIR(NJ - 1, 3, EXF) S5_PAIR(NJ - 1, 4, EXF) S5_PAIR(NJ - 1, 5, EXF) S5_PAIR(NJ - 1, 6, EXF) S5_PAIR(NJ - 1, 7, EXF) \
       }
+#if S5_EXSPLIT
+      if (have_ex) { S5_PAIRS(true) } else { S5_PAIRS(false) }
+#else
+      S5_PAIRS(true)
+#endif
+#undef S5_PAIRS
 #undef S5_PAIR
     }
     if constexpr (DBG == 4) t_ladder += __builtin_amdgcn_s_memtime() - ti1;
     if constexpr (DBG == 3) t_ladder += __builtin_amdgcn_s_memtime() - t_mid;
+    if (tl == next_rf) {
+      // every later item has a larger index than the k buffered items at or above the bound: it needs a strictly larger score
+      const float tk = s5_kth_of_32(cm, k);
+      thr = tk > thr ? tk : thr;
+      const int gap = (tl + 2) >> 1;
+      next_rf = tl + (gap < S5_RF ? gap : S5_RF);
+      if constexpr (DBG == 4) ++n_cand;
+    }
   }
 #undef S5_TILE_BODY
 
@@ -598,40 +636,78 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       d[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;
     }
   }
-  // final selection + output of the wave's 32 users: the lane that holds the entry of rank j writes output position j
-  const int cnt_fin = (pos - lane_base) >> 3;
-  for (int u = 0; u < 32; ++u) {
-    const long ur = row0 + wave * 32 + u;
-    if (ur >= Bu) break;
-    const int n0 = __builtin_amdgcn_readlane(cnt_fin, u), n1 = __builtin_amdgcn_readlane(cnt_fin, u + 32);
-    unsigned long long* b0 = wgb + (long)u * (2 * S5_CAPH);
-    unsigned long long e[2];
-    bool kp[2];
-    s5_select(b0, b0 + S5_CAPH, n0, n1, k, lane, e, kp);
-    int rk[2] = {0, 0};
+  // fill counts and final thresholds of the wave's 64 buffer halves: the final selection + ranking is score_topk_finalize_kernel's
+  {
+    int2 o;
+    o.x = (pos - lane_base) >> 3;
+    o.y = (int)__float_as_uint(thr);
+    reinterpret_cast<int2*>(cnt_out)[(row0 + (long)wave * 32 + l31) * 2 + half] = o;
+  }
+}
+
+// ---- final selection: one wave per user, four users per workgroup. Only buffered candidates at or above the user's final
+// threshold can be among its k best (k buffered items lie at or above it): they are filtered first (~25 of ~110), gathered into one
+// entry per lane through LDS, ranked by counting (score desc, item index asc) and the lanes of rank < k write the output. More than
+// 64 survivors (ties at the threshold) or a threshold that never rose: the general selection (s5_select: bitwise binary search over
+// ballot counts) picks the k best first. Empty slots (-inf, -1) behind fewer than k candidates.
+__global__ __launch_bounds__(256) void score_topk_finalize_kernel(long Bu, int k, const int* __restrict__ cnt, unsigned long long* __restrict__ gbuf,
+                                                                  float* __restrict__ out_val, int* __restrict__ out_idx) {
+  __shared__ unsigned long long stage[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long ur = (long)blockIdx.x * 4 + w;
+  if (ur >= Bu) return;                                      // wave-uniform
+  const int4 c = reinterpret_cast<const int4*>(cnt)[ur];     // (n0, thr bits, n1, thr bits) of the user's two halves
+  const int n0 = __builtin_amdgcn_readfirstlane(c.x), n1 = __builtin_amdgcn_readfirstlane(c.z);
+  const float thr = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane(c.y));
+  unsigned long long* b0 = gbuf + ur * (2 * S5_CAPH);
+  unsigned long long* b1 = b0 + S5_CAPH;
+  // ---- filter + gather
+  const int c0 = (n0 + 63) >> 6, c1 = (n1 + 63) >> 6;
+  int total = 0;
+  bool fits = true;
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      const int h32 = (int)(e[part] >> 32), l32 = (int)e[part];
-      for (unsigned long long m = __ballot(kp[part]); m; m &= m - 1ull) {
-        const int j = __ffsll((long long)m) - 1;
-        const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(h32, j) << 32) |
-                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(l32, j);
-        rk[0] += kj > e[0];
-        rk[1] += kj > e[1];
-      }
+  for (int j = 0; j < 2 * S5_EH; ++j) {
+    const bool first = j < S5_EH;
+    const int jj = first ? j : j - S5_EH;
+    if (jj < (first ? c0 : c1)) {                            // wave-uniform
+      const int q = lane + 64 * jj;
+      const unsigned long long raw = q < (first ? n0 : n1) ? (first ? b0 : b1)[q] : 0ull;
+      const bool keep = q < (first ? n0 : n1) && __uint_as_float((unsigned int)(raw >> 32)) >= thr;
+      const unsigned long long m = __ballot(keep);
+      const int p = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+      if (keep && p < 64) stage[w][p] = raw;
+      total += __popcll(m);
+      fits = fits && total <= 64;
     }
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      if (kp[part]) {
-        out_val[ur * k + rk[part]] = st_key2f((unsigned int)(e[part] >> 32));
-        out_idx[ur * k + rk[part]] = (int)(0xFFFFFFFFu - (unsigned int)(e[part] & 0xFFFFFFFFull));
-      }
-    }
-    const int n = n0 + n1;
-    if (lane >= n && lane < k) {                             // fewer than k candidates: empty slots behind them
-      out_val[ur * k + lane] = -INFINITY;
-      out_idx[ur * k + lane] = -1;
-    }
+  }
+  unsigned long long raw = 0ull;
+  int n;
+  if (fits) {
+    n = total;
+    st_wave_fence();                                         // LDS operations of a wave execute in order
+    raw = lane < n ? stage[w][lane] : 0ull;
+  } else {
+    s5_select<false>(b0, b1, n0, n1, k, lane);
+    n = n0 + n1 < k ? n0 + n1 : k;                           // survivors, in b0[0 .. n)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    raw = lane < n ? b0[lane] : 0ull;
+  }
+  const unsigned long long e = lane < n ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw >> 32))) << 32) | (raw & 0xFFFFFFFFull)) : 0ull;
+  const int h32 = (int)(e >> 32), l32 = (int)e;
+  int rk = 0;
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long kj = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(h32, j) << 32) |
+                                  (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(l32, j);
+    rk += kj > e;
+  }
+  const int nk = n < k ? n : k;
+  if (lane < n && rk < k) {
+    out_val[ur * k + rk] = st_key2f((unsigned int)(e >> 32));
+    out_idx[ur * k + rk] = (int)(0xFFFFFFFFu - (unsigned int)(e & 0xFFFFFFFFull));
+  }
+  if (lane >= nk && lane < k) {                              // fewer than k candidates: empty slots behind them
+    out_val[ur * k + lane] = -INFINITY;
+    out_idx[ur * k + lane] = -1;
   }
 }
 
@@ -772,75 +848,93 @@ static int s5_pick_waves(long Bu) {
   return (int)(w < 1 ? 1 : (w > S5_MAXW ? S5_MAXW : w));
 }
 
-// exclusion-event region of the workspace (16-byte aligned pieces): group_base int[G + 1], grp_cnt int[G], row_cnt int[Bu],
-// row_lo long[Bu], events uint[excl_nnz + 11 G] (per group: its events rounded up to a quad + two padding quads)
+// Exclusion events of one (user list, exclusion CSR, item range, tile width) combination: group_base int[G + 1], grp_cnt int[G],
+// row_cnt int[Bu], row_lo long[Bu], events uint[excl_nnz + 11 G] (per group: its events rounded up to a quad + two padding quads),
+// 16-byte aligned pieces of ONE caller-owned buffer of sbr_score_topk_f16_events_bytes(Bu, excl_nnz) bytes. The exclusion mask of an
+// evaluation split is the same for every evaluation (eval/eval.py:219: dataset.exclude_data), so a caller builds the stream once
+// per (split, user chunk, item shard) and hands it to every later call (build_events = 0).
 static long s5_al16(long b) { return (b + 15) & ~15L; }
 static long s5_event_bytes(long Bu, long excl_nnz) {
   if (excl_nnz <= 0) return 0;
   const long G = sbr_cdiv(Bu, 32);
   return s5_al16((G + 1) * 4) + s5_al16(G * 4) + s5_al16(Bu * 4) + s5_al16(Bu * 8) + s5_al16((excl_nnz + 11 * G) * 4) + 16;
 }
+extern "C" long sbr_score_topk_f16_events_bytes(long Bu, long excl_nnz) { return s5_event_bytes(Bu, excl_nnz); }
 
-static long s5_workspace_bytes(long Bu, long excl_nnz) {
-  // users padded to whole workgroups of any wave count (< 32 * S5_MAXW extra) + the cycle stamps of SBR_ST_DEBUG + the events
-  const long padded = Bu + 32L * S5_MAXW;
-  return padded * 2 * S5_CAPH * 8 + (sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L + s5_event_bytes(Bu, excl_nnz);
+static long s5_padded_users(long Bu) { return Bu + 32L * S5_MAXW; }      // users padded to whole workgroups of any wave count
+static long s5_workspace_bytes(long Bu) {
+  // candidate buffers + fill counts + the cycle stamps of SBR_ST_DEBUG
+  const long padded = s5_padded_users(Bu);
+  return padded * 2 * S5_CAPH * 8 + s5_al16(padded * 2 * 8) + s5_al16((sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L);
+}
+
+struct S5Events { const unsigned int* events; const int* group_base; };
+
+// builds the event stream into `buf` (three launches on `s`); tile_items = 32 * NJ of the kernel that will read it
+static int s5_build_events(void* buf, long buf_bytes, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
+                           int item_offset, int tile_items, bool build, S5Events* out, hipStream_t s) {
+  SBR_REQUIRE(buf && buf_bytes >= s5_event_bytes(Bu, excl_nnz), "sbr_score_topk_f16: event buffer of %ld bytes needed (sbr_score_topk_f16_events_bytes), %ld given",
+              s5_event_bytes(Bu, excl_nnz), buf_bytes);
+  const long G = sbr_cdiv(Bu, 32);
+  const int n_tiles_ev = sbr_cdiv(I, tile_items);
+  SBR_REQUIRE((long)n_tiles_ev * 4 <= 150 * 1024 && n_tiles_ev < (1 << 21) - 1,
+              "sbr_score_topk_f16: %d item tiles exceed the event builder's LDS histogram (score the catalogue in item shards)", n_tiles_ev);
+  char* p = (char*)s5_al16((long)buf);
+  int* gb = (int*)p; p += s5_al16((G + 1) * 4);
+  int* gc = (int*)p; p += s5_al16(G * 4);
+  int* rc = (int*)p; p += s5_al16(Bu * 4);
+  long* rl = (long*)p; p += s5_al16(Bu * 8);
+  unsigned int* ev = (unsigned int*)p;
+  out->events = ev;
+  out->group_base = gb;
+  if (!build) return SBR_OK;
+  const long cap = excl_nnz + 11 * G;
+  if (hipMemsetAsync(gc, 0, G * 4, s) != hipSuccess) { sbr_set_error("sbr_score_topk_f16: memset failed"); return SBR_ERR_HIP; }
+  s5_ev_rows_kernel<<<(unsigned int)sbr_cdiv(Bu, 256), 256, 0, s>>>(Bu, u_idx, eptr, eidx, item_offset, I, rl, rc, gc);
+  s5_ev_scan_kernel<<<1, 1024, 0, s>>>((int)G, gc, gb);
+  static bool lds_raised = false;
+  if (!lds_raised) {
+    if (hipFuncSetAttribute((const void*)s5_ev_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+      sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit of the event builder");
+      return SBR_ERR_HIP;
+    }
+    lds_raised = true;
+  }
+  s5_ev_scatter_kernel<<<(unsigned int)G, 256, (size_t)n_tiles_ev * 4, s>>>(Bu, eidx, item_offset, tile_items, n_tiles_ev, rl, rc, gc, gb, ev, cap);
+  SBR_CHECK_LAUNCH("sbr_score_topk_f16 (exclusion events)");
+  return SBR_OK;
 }
 
 template <int KS, int NS, int NJ, bool PRE>
 static int s5_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
-                     int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
+                     int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, void* ev_buf,
+                     long ev_bytes, int build_events, hipStream_t s) {
   const int W = s5_pick_waves(Bu);
   const long n_wg = sbr_cdiv(Bu, 32L * W);
-  const long need = n_wg * 32L * W * 2 * S5_CAPH * 8;
-  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2: timing-only ablations, 4: cycle stamps
-  const long dbg_bytes = s5_al16(n_wg * S5_MAXW * 64L);
+  const long padded = s5_padded_users(Bu);
+  const long buf_bytes = padded * 2 * S5_CAPH * 8, cnt_bytes = s5_al16(padded * 2 * 8);
+  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2 | 5 | 6 | 7: timing-only ablations, 4: cycle stamps
+  SBR_REQUIRE(n_wg * 32L * W <= padded, "sbr_score_topk_f16: internal: padding");
+  SBR_REQUIRE(workspace && workspace_bytes >= s5_workspace_bytes(Bu),
+              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", s5_workspace_bytes(Bu), workspace_bytes);
+  int* cnt = (int*)((char*)workspace + buf_bytes);
+  void* dbg_buf = (char*)workspace + buf_bytes + cnt_bytes;
   const bool with_excl = eptr != nullptr && excl_nnz > 0;
-  SBR_REQUIRE(workspace && workspace_bytes >= need + dbg_bytes + s5_event_bytes(Bu, with_excl ? excl_nnz : 0),
-              "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given",
-              need + dbg_bytes + s5_event_bytes(Bu, with_excl ? excl_nnz : 0), workspace_bytes);
-  void* dbg_buf = (char*)workspace + need;
-  const unsigned int* events = nullptr;
-  const int* group_base = nullptr;
+  S5Events evs = {nullptr, nullptr};
   if (with_excl) {
-    // event stream of this call (three launches in front of the scorer on the same stream)
-    const long G = sbr_cdiv(Bu, 32);
-    const int n_tiles_ev = sbr_cdiv(I, 32 * NJ);
-    SBR_REQUIRE((long)n_tiles_ev * 4 <= 150 * 1024 && n_tiles_ev < (1 << 21) - 1,
-                "sbr_score_topk_f16: %d item tiles exceed the event builder's LDS histogram (score the catalogue in item shards)", n_tiles_ev);
-    char* p = (char*)s5_al16((long)((char*)workspace + need + dbg_bytes));
-    int* gb = (int*)p; p += s5_al16((G + 1) * 4);
-    int* gc = (int*)p; p += s5_al16(G * 4);
-    int* rc = (int*)p; p += s5_al16(Bu * 4);
-    long* rl = (long*)p; p += s5_al16(Bu * 8);
-    unsigned int* ev = (unsigned int*)p;
-    const long cap = excl_nnz + 11 * G;
-    if (hipMemsetAsync(gc, 0, G * 4, s) != hipSuccess) { sbr_set_error("sbr_score_topk_f16: memset failed"); return SBR_ERR_HIP; }
-    s5_ev_rows_kernel<<<(unsigned int)sbr_cdiv(Bu, 256), 256, 0, s>>>(Bu, u_idx, eptr, eidx, item_offset, I, rl, rc, gc);
-    s5_ev_scan_kernel<<<1, 1024, 0, s>>>((int)G, gc, gb);
-    static bool lds_raised = false;
-    if (!lds_raised) {
-      if (hipFuncSetAttribute((const void*)s5_ev_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-        sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit of the event builder");
-        return SBR_ERR_HIP;
-      }
-      lds_raised = true;
-    }
-    s5_ev_scatter_kernel<<<(unsigned int)G, 256, (size_t)n_tiles_ev * 4, s>>>(Bu, eidx, item_offset, 32 * NJ, n_tiles_ev, rl, rc, gc, gb, ev, cap);
-    SBR_CHECK_LAUNCH("sbr_score_topk_f16 (exclusion events)");
-    events = ev;
-    group_base = gb;
+    const int rc = s5_build_events(ev_buf, ev_bytes, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, 32 * NJ, build_events != 0, &evs, s);
+    if (rc) return rc;
   }
   const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + 2 * NS * 4 + 16;
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
-  // prefix pass: ~1/12 (D = 256: 1/24) of the catalogue (whole tiles), skipped for catalogues too short to repay it; SBR_ST_PRE overrides (tiles)
+  // prefix pass (class maxima only, no appends) over the first S5_PRE_TILES tiles: its bound spares the main pass the appends of its
+  // first tiles (every score passes a threshold of -inf), at the price of scoring those tiles twice (measured on c2: 0 tiles 1.76 ms,
+  // 8: 1.59, 16: 1.54, 32: 1.55, 65: 1.58); SBR_ST_PRE overrides (tiles, lab)
   const int n_tiles = sbr_cdiv(I, 32 * NJ);
-  int n_pre = n_tiles >= 96 ? n_tiles / (NJ == 1 ? 24 : 12) : 0;   // (D = 256, 32-item tiles: 1/24 measured best, 1.625 vs 1.639 ms)
+  int n_pre = n_tiles >= 96 ? S5_PRE_TILES : 0;
   if (getenv("SBR_ST_PRE")) n_pre = atoi(getenv("SBR_ST_PRE"));
   if (n_pre > n_tiles) n_pre = n_tiles;
-  if (n_pre < 0 || !PRE || k > 24) n_pre = 0;             // the bound is the k-th of 32 class maxima: needs k below that
-  // 1 | 2 | 5 | 6 | 7: timing-only ablations (1: MFMA loop only; 2: + threshold compares; of the MFMA loop 5: without loads and
-  // hand-off, 6: without fragment reads, 7: without MFMAs), 4: cycle stamps
+  if (n_pre < 0 || !PRE) n_pre = 0;
   auto kern = dbg == 1 ? score_topk_f16_n_kernel<KS, NS, NJ, 1, PRE> : (dbg == 2 ? score_topk_f16_n_kernel<KS, NS, NJ, 2, PRE> :
               (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : (dbg == 3 ? score_topk_f16_n_kernel<KS, NS, NJ, 3, PRE> : (dbg == 5 ? score_topk_f16_n_kernel<KS, NS, NJ, 5, PRE> :
               (dbg == 6 ? score_topk_f16_n_kernel<KS, NS, NJ, 6, PRE> : (dbg == 7 ? score_topk_f16_n_kernel<KS, NS, NJ, 7, PRE> :
@@ -849,35 +943,41 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, events, group_base, item_offset, k,
-                                                   n_pre, W, out_val, out_idx, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
+  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, evs.events, evs.group_base, item_offset, k,
+                                                   n_pre, W, cnt, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
+  score_topk_finalize_kernel<<<(unsigned int)sbr_cdiv(Bu, 4), 256, 0, s>>>(Bu, k, cnt, (unsigned long long*)workspace, out_val, out_idx);
+  SBR_CHECK_LAUNCH("sbr_score_topk_f16 (final selection)");
   return SBR_OK;
 }
 
 // D in {64, 128, 256}
 static int s5_dispatch(const void* U, const void* It, int D, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
-                int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, hipStream_t s) {
+                       int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, void* ev_buf, long ev_bytes,
+                       int build_events, hipStream_t s) {
   switch (D) {
-    case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 128: return s5_launch<8, S5_NS, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
-    case 256: return s5_launch<16, S5_NS, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, s);
+    case 64: return s5_launch<4, 8, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, ev_buf, ev_bytes, build_events, s);
+    case 128: return s5_launch<8, S5_NS, 2, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, ev_buf, ev_bytes, build_events, s);
+    case 256: return s5_launch<16, S5_NS, 1, true>(U, It, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, k, out_val, out_idx, workspace, workspace_bytes, ev_buf, ev_bytes, build_events, s);
     default:
       sbr_set_error("sbr_score_topk_f16: D=%d not supported by the narrow-wave kernel", D);
       return SBR_ERR_ARG;
   }
 }
 
-// bytes of the workspace of one call: candidate buffers (users padded to whole workgroups), cycle stamps of SBR_ST_DEBUG, and the
-// exclusion-event region
-extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k, long excl_nnz) {
+// bytes of the workspace of one call: candidate buffers (users padded to whole workgroups), fill counts, cycle stamps of SBR_ST_DEBUG
+extern "C" long sbr_score_topk_f16_workspace(long Bu, int I, int k) {
   (void)I; (void)k;
-  return s5_workspace_bytes(Bu, excl_nnz);
+  return s5_workspace_bytes(Bu);
 }
 
+// events / events_bytes: caller-owned buffer of sbr_score_topk_f16_events_bytes(Bu, excl_nnz) bytes (NULL without exclusions);
+// build_events != 0: the event stream of (u_idx, exclusion CSR, item range, D) is built into it first (three small launches),
+// 0: it holds the stream a previous call with the same (u_idx, CSR, item_offset, I, D) built.
 extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int I, const long* u_idx,
                                   const long* excl_indptr, const int* excl_indices, long excl_nnz, int item_offset, int k, float* out_val,
-                                  int* out_idx, void* workspace, long workspace_bytes, void* stream) {
+                                  int* out_idx, void* workspace, long workspace_bytes, void* events, long events_bytes, int build_events,
+                                  void* stream) {
   SBR_REQUIRE(k >= 1 && k <= 32, "sbr_score_topk_f16: k=%d outside [1, 32] (use sbr_gemm_f32 + sbr_topk_rows)", k);
   SBR_REQUIRE(I >= 1, "sbr_score_topk_f16: empty catalogue");
   if (Bu == 0) return SBR_OK;
@@ -885,7 +985,7 @@ extern "C" int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, l
   SBR_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), "sbr_score_topk_f16: exclusion CSR must be given whole or not at all");
   SBR_REQUIRE(D == 64 || D == 128 || D == 256, "sbr_score_topk_f16: D=%d not supported (64, 128, 256)", D);
   return s5_dispatch(U_f16, I_f16, D, Bu, I, u_idx, excl_indptr, excl_indices, excl_nnz, item_offset, k, out_val, out_idx, workspace,
-                     workspace_bytes, (hipStream_t)stream);
+                     workspace_bytes, events, events_bytes, build_events, (hipStream_t)stream);
 }
 
 __global__ void cast_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Y, long n) {

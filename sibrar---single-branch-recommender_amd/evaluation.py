@@ -308,7 +308,17 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
             u_idxs = torch.from_numpy(users[s:s + bs].astype(np.int64)).to(device)
             u_repr = alg.get_user_representations(u_idxs)
             if scorer == 'fp16_fused' and torch.is_tensor(u_repr):
-                val, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1], item_offset=lo)
+                # the split's exclusion mask in the scorer's layout, built once per (user chunk, item shard, D) and kept with the
+                # split like the resident CSR it is made from
+                cache = getattr(dataset, '_scorer_excl', None)
+                if cache is None or cache.get('csr') is not excl:
+                    cache = {'csr': excl}
+                    try:
+                        dataset._scorer_excl = cache
+                    except Exception:
+                        pass
+                holder = cache.setdefault((s, int(u_idxs.numel()), lo, hi, int(i16.shape[1])), ops.ScorerExclusions())
+                val, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1], item_offset=lo, exclusions=holder)
             else:
                 out = alg.combine_user_item_representations(u_repr, i_repr)
                 ops.mask_scores_(out, u_idxs, excl[0], excl[1], item_offset=lo if sharded else None)

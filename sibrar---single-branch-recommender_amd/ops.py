@@ -742,18 +742,39 @@ def cast_f16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+class ScorerExclusions:
+    """The exclusion mask of one (user list, exclusion CSR, item range) combination in the layout the fused scorer reads (a
+    wave-uniform event stream, csrc/score_topk_f16_n.hip). The mask of an evaluation split never changes (eval/eval.py:219:
+    ``dataset.exclude_data``), so ``evaluation.evaluate_recommender_algorithm`` keeps one of these per (split, user chunk, item
+    shard) next to the resident CSR and every evaluation after the first skips the three builder launches. The first
+    ``score_topk_f16`` call that receives the object builds the stream; later calls must pass the same u_idx / CSR / item range / D."""
+
+    def __init__(self):
+        self.buf, self.key = None, None
+
+
 def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, excl_indptr=None, excl_indices=None,
-                   item_offset: int = 0):
+                   item_offset: int = 0, exclusions: 'ScorerExclusions' = None):
     _need_cuda(u16, i16)
     Bu, D = u16.shape
     I = i16.shape[0]
     val = torch.empty(Bu, k, device=u16.device, dtype=torch.float32)
     idx = torch.empty(Bu, k, device=u16.device, dtype=torch.int32)
     nnz = 0 if excl_indices is None else int(excl_indices.numel())
-    ws = torch.empty(max(int(lib().sbr_score_topk_f16_workspace(Bu, I, k, nnz)), 8), device=u16.device, dtype=torch.uint8)
+    ws = torch.empty(max(int(lib().sbr_score_topk_f16_workspace(Bu, I, k)), 8), device=u16.device, dtype=torch.uint8)
+    ev, build = None, 1
+    if nnz > 0:
+        key = (Bu, I, D, int(item_offset), nnz)
+        holder = exclusions if exclusions is not None else ScorerExclusions()
+        if holder.buf is not None and holder.key == key:
+            build = 0                          # built by an earlier call for the same users / mask / item range (the caller's promise)
+        else:
+            holder.buf = torch.empty(int(lib().sbr_score_topk_f16_events_bytes(Bu, nnz)) + 16, device=u16.device, dtype=torch.uint8)
+            holder.key = key
+        ev = holder.buf
     _timed(('score_topk_f16', Bu, I, D, k),
            lambda: call('sbr_score_topk_f16', ptr(u16), ptr(i16), D, Bu, I, ptr(u_idx), ptr(excl_indptr), ptr(excl_indices), nnz,
-                        item_offset, k, ptr(val), ptr(idx), ptr(ws), ws.numel(), stream()))
+                        item_offset, k, ptr(val), ptr(idx), ptr(ws), ws.numel(), ptr(ev), 0 if ev is None else ev.numel(), build, stream()))
     return val, idx
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r' T (sbr_\w+)', out))
     assert set(protos) <= exported, set(protos) - exported
     assert exported <= set(protos), f'exported but undeclared: {exported - set(protos)}'
-    assert handle.sbr_abi_version() == 2
+    assert handle.sbr_abi_version() == 3
     assert handle.sbr_last_error() is not None
 
 

@@ -17,14 +17,14 @@ K = 20
 g = torch.Generator(device='cuda').manual_seed(1)
 u = (torch.randn(Bu, D, device='cuda', generator=g) / 8).half()
 it = (torch.randn(I, D, device='cuda', generator=g) / 8).half()
-need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K, 0))
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K))
 ws = torch.zeros(need + (1 << 20), dtype=torch.uint8, device='cuda')
 val = torch.empty(Bu, K, device='cuda'); idx = torch.empty(Bu, K, dtype=torch.int32, device='cuda')
 
 
 def launch():
     L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, K, val.data_ptr(), idx.data_ptr(),
-           ws.data_ptr(), ws.numel(), L.stream())
+           ws.data_ptr(), ws.numel(), None, 0, 1, L.stream())
 
 
 def timed(env, reps=15, warm=10):

@@ -24,15 +24,17 @@ with torch.no_grad():
 print('user repr abs mean %.3g, item repr abs mean %.3g, item norm cv %.3g' % (float(u16.float().abs().mean()), float(i16.float().abs().mean()),
       float(i16.float().norm(dim=1).std() / i16.float().norm(dim=1).mean())))
 Bu, I, D = u16.shape[0], i16.shape[0], u16.shape[1]
-need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K, int(excl[1].numel())))
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, K))
 ws = torch.zeros(need + (1 << 20), dtype=torch.uint8, device=dev)
 val = torch.empty(Bu, K, device=dev); idx = torch.empty(Bu, K, dtype=torch.int32, device=dev)
 
 
 def timed(u, it, ex, warm=10, reps=20):
+    evb = torch.empty(int(L.lib().sbr_score_topk_f16_events_bytes(Bu, int(ex[1].numel()))) + 16, dtype=torch.uint8, device=dev) if ex else None
     def launch():
         L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, users.data_ptr() if ex else None, ex[0].data_ptr() if ex else None,
-               ex[1].data_ptr() if ex else None, int(ex[1].numel()) if ex else 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+               ex[1].data_ptr() if ex else None, int(ex[1].numel()) if ex else 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(),
+               evb.data_ptr() if ex else None, evb.numel() if ex else 0, 1, L.stream())
     for _ in range(warm): launch()
     evs = []
     for _ in range(reps):
@@ -47,7 +49,7 @@ def candidates(u, it):
     os.environ['SBR_ST_DEBUG'] = '4'
     ws.zero_()
     for _ in range(2):
-        L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+        L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, K, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0, 1, L.stream())
     torch.cuda.synchronize()
     os.environ.pop('SBR_ST_DEBUG')
     units = -(-Bu // 32); W = max(1, min(14, -(-units // 256)))

@@ -17,11 +17,11 @@ u = (torch.randn(Bu, D, device='cuda', generator=g) / 8).half()
 it = (torch.randn(I, D, device='cuda', generator=g) / 8).half()
 rows = 448 if wide else 224
 nwg = (Bu + rows - 1) // rows
-need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, 20, 0))
+need = int(L.lib().sbr_score_topk_f16_workspace(Bu, I, 20))
 ws = torch.zeros(max(need, nwg * 7 * 64), dtype=torch.uint8, device='cuda')
 val = torch.empty(Bu, 20, device='cuda'); idx = torch.empty(Bu, 20, dtype=torch.int32, device='cuda')
 for _ in range(2):
-    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, 20, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+    L.call('sbr_score_topk_f16', u.data_ptr(), it.data_ptr(), D, Bu, I, None, None, None, 0, 0, 20, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0, 1, L.stream())
 torch.cuda.synchronize()
 stamps = ws[need - nwg * 7 * 64:need] if wide else ws[:nwg * 7 * 64]
 d = stamps.view(torch.int64).cpu().numpy().reshape(nwg * 7, 8).astype(np.float64)
