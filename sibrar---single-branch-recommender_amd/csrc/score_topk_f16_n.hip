@@ -63,8 +63,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef S5_PRE_TILES
 #define S5_PRE_TILES 16                  // tiles of the prefix pass (class maxima only, no appends) of catalogues of >= 96 tiles
 #endif
+#ifndef S5_CML_KS
+#define S5_CML_KS 16                     // class maxima of the main pass in LDS for D >= 16 * S5_CML_KS (else in registers)
+#endif
 #ifndef S5_EXSPLIT
-#define S5_EXSPLIT 1                     // 1: tiles without exclusion events append without testing exclusion bits (two code copies)
+#define S5_EXSPLIT 0                     // 1: tiles without exclusion events append without testing exclusion bits (two code copies;
+                                         // measured slower: the copies cost eight register moves of the class maxima per tile)
 #endif
 #ifndef S5_RF
 #define S5_RF 32                         // tiles between two threshold refreshes in the steady state
@@ -148,6 +152,64 @@ __device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long
   return t == t ? t : -INFINITY;
 }
 
+// The same selection for the scorer's OVERFLOW path (a (user, half) buffer ran full: ties at the threshold, or a threshold that
+// cannot rise), written for few registers instead of speed — the entries are re-read from the buffers in every round of the search
+// instead of being held in 2 x S5_EH register pairs per lane, which would cost the hot loop its fourth wave per SIMD. Survivors go
+// back split over both halves (k - k / 2 and k / 2: both keep room). Returns the k-th best score; -inf (nothing moved) below k entries.
+__device__ __forceinline__ float s5_overflow_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane) {
+  const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // written and read by this wave only
+  if (n0 + n1 < k) return -INFINITY;
+  const int c0 = (n0 + 63) >> 6, c1 = (n1 + 63) >> 6;
+  auto raw_at = [&](bool first, int j) -> unsigned long long {
+    const int q = lane + 64 * j;
+    return q < (first ? n0 : n1) ? (first ? b0 : b1)[q] : 0ull;
+  };
+  auto key_of = [&](unsigned long long raw) -> unsigned long long {     // 0 for an empty slot (raw entries are never 0: ~item != 0)
+    return raw ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw >> 32))) << 32) | (raw & 0xFFFFFFFFull)) : 0ull;
+  };
+  auto count_ge = [&](unsigned long long C) {
+    int cnt = 0;
+    for (int j = 0; j < c0; ++j) cnt += __popcll(__ballot(key_of(raw_at(true, j)) >= C));
+    for (int j = 0; j < c1; ++j) cnt += __popcll(__ballot(key_of(raw_at(false, j)) >= C));
+    return cnt;
+  };
+  unsigned int T = 0u;
+  int c_ge = n0 + n1;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    const int cnt = count_ge((unsigned long long)trial << 32);
+    if (cnt >= k) { T = trial; c_ge = cnt; if (cnt == k) break; }
+  }
+  unsigned long long C = (unsigned long long)T << 32;
+  if (c_ge != k) {
+    unsigned int Lw = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = Lw | (1u << bit);
+      Lw = count_ge(((unsigned long long)T << 32) | trial) >= k ? trial : Lw;
+    }
+    C |= (unsigned long long)Lw;
+  }
+  // survivors land in entries [0, 32) of the two halves: chunk 0 of both is taken into registers first, the other chunks are
+  // streamed (read, keep, store), chunk 0's survivors go last
+  const unsigned long long r00 = raw_at(true, 0), r10 = raw_at(false, 0);
+  const int kh = k - (k >> 1);
+  int before = 0;
+  auto place = [&](unsigned long long raw) {
+    const bool keep = key_of(raw) >= C;
+    const unsigned long long m = __ballot(keep);
+    const int p = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (keep) (p < kh ? b0 + p : b1 + (p - kh))[0] = raw;
+    before += __popcll(m);
+  };
+  for (int j = 1; j < c0; ++j) place(raw_at(true, j));
+  for (int j = 1; j < c1; ++j) place(raw_at(false, j));
+  place(r00);
+  place(r10);
+  const float t = st_key2f(T);
+  return t == t ? t : -INFINITY;
+}
+
 // append of one raw candidate entry at byte offset `pos` of the wave's buffer block (`block`: wave-uniform, so the descriptor is
 // four SGPRs the compiler builds once per kernel): buffer_store_dwordx2 v[ent], v[pos], s[rsrc], 0 offen
 __device__ __forceinline__ void s5_append(unsigned long long* block, int pos, u32x2 ent) {
@@ -193,9 +255,27 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #else
 #define S5_STORE_ASM "buffer_store_dword %[tmp], %[pos], %[rs], 0 offen\n\t" "buffer_store_dword %[a], %[pos], %[rs], 0 offen offset:4\n\t"
 #endif
-template <unsigned int BIT, int C, bool EX>
-__device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs, float& cmax) {
+// CML (D = 256: the user fragments alone take 64 registers): the class maxima live in LDS ([register][lane] floats per wave, the lane's
+// slot of class r at cm_addr + 256 r) and the append updates them with a no-return ds_max_f32 under the same EXEC mask.
+template <unsigned int BIT, int C, bool EX, bool CML, int R>
+__device__ __forceinline__ void s5_try_append(float a, float thr, unsigned int ex, int& pos, unsigned int il, i32x4 rs, float& cmax,
+                                              unsigned int cm_addr) {
   unsigned int tmp;
+  if constexpr (CML) {
+    asm volatile(
+        "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
+        "v_and_b32_e32 %[tmp], %[bit], %[ex]\n\t"
+        "v_cmpx_eq_u32_e32 0, %[tmp]\n\t"
+        "v_subrev_u32_e32 %[tmp], %[c], %[il]\n\t"
+        S5_STORE_ASM
+        "v_add_u32_e32 %[pos], 8, %[pos]\n\t"
+        "ds_max_f32 %[cma], %[a] offset:%[off]\n\t"
+        "s_mov_b64 exec, -1"
+        : [pos] "+v"(pos), [tmp] "=&v"(tmp)
+        : [a] "v"(a), [thr] "v"(thr), [ex] "v"(ex), [il] "v"(il), [rs] "s"(rs), [bit] "n"(BIT), [c] "n"(C), [cma] "v"(cm_addr), [off] "n"(R * 256)
+        : "vcc", "memory");
+    return;
+  }
   if constexpr (!EX) {                                       // a tile without exclusion events: no exclusion bit to test
     asm volatile(
         "v_cmpx_gt_f32_e32 %[a], %[thr]\n\t"
@@ -308,9 +388,12 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   constexpr int LFL = LFL0 * PER_T <= 63 ? LFL0 : 63 / PER_T;
   static_assert(LFL >= 1 && LFL * PER_T <= 63, "vmcnt field");
   static_assert(LIMIT >= 32, "k <= 32 entries must fit below the compaction limit");
+  constexpr bool CML = KS >= S5_CML_KS;                    // class maxima of the main pass in LDS instead of registers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   lds_int* full_lds = (lds_int*)(smem + NS * TILEB);
   lds_int* free_lds = full_lds + NS;
+  // CML: [consumer wave][16 classes][64 lanes] floats behind the ring and its counters
+  const unsigned int cm_addr = (unsigned int)(size_t)(smem + NS * TILEB + 2 * NS * 4 + 16) + (unsigned int)((threadIdx.x >> 6) * 4096 + (threadIdx.x & 63) * 4);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -527,6 +610,10 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;       // the main pass keeps the class maxima of what it APPENDS
     S5_EV_RESTART()                                        // the main pass starts again from the first tile
   }
+  if constexpr (CML) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *(__attribute__((address_space(3))) float*)(size_t)(cm_addr + r * 256) = -INFINITY;
+  }
 
   // ---- pass 2: all tiles, lane-local threshold filter and appends ----
   const int pos_limit = lane_base + LIMIT * 8;
@@ -545,7 +632,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         need &= need - 1ull;
         const int n0 = __builtin_amdgcn_readlane(cnt, u), n1 = __builtin_amdgcn_readlane(cnt, u + 32);
         unsigned long long* b0 = wgb + (long)u * (2 * S5_CAPH);
-        const float nt = s5_select<true>(b0, b0 + S5_CAPH, n0, n1, k, lane);
+        const float nt = s5_overflow_select(b0, b0 + S5_CAPH, n0, n1, k, lane);
         if (n0 + n1 >= k && l31 == u) {
           thr = nt > thr ? nt : thr;
           pos = lane_base + (half ? (k >> 1) : k - (k >> 1)) * 8;
@@ -599,8 +686,8 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       // wave an instruction-fetch bubble, sixteen of them per tile)
 #define S5_PAIR(NJI, G, EXF)                                                                                             \
       if (__builtin_expect(gm[(NJI) * 8 + (G)] != 0ull, 0)) {                                                            \
-        s5_try_append<(1u << ((NJI) * 16 + 2 * (G))), (NJI) * 32 + ((2 * (G)) & 3) + 8 * ((2 * (G)) >> 2), EXF>(acc[NJI][2 * (G)], thr, ex, pos, item_lane, wrs, cm[2 * (G)]);             \
-        s5_try_append<(1u << ((NJI) * 16 + 2 * (G) + 1)), (NJI) * 32 + ((2 * (G) + 1) & 3) + 8 * ((2 * (G) + 1) >> 2), EXF>(acc[NJI][2 * (G) + 1], thr, ex, pos, item_lane, wrs, cm[2 * (G) + 1]); \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G))), (NJI) * 32 + ((2 * (G)) & 3) + 8 * ((2 * (G)) >> 2), EXF, CML, 2 * (G)>(acc[NJI][2 * (G)], thr, ex, pos, item_lane, wrs, cm[2 * (G)], cm_addr);             \
+        s5_try_append<(1u << ((NJI) * 16 + 2 * (G) + 1)), (NJI) * 32 + ((2 * (G) + 1) & 3) + 8 * ((2 * (G) + 1) >> 2), EXF, CML, 2 * (G) + 1>(acc[NJI][2 * (G) + 1], thr, ex, pos, item_lane, wrs, cm[2 * (G) + 1], cm_addr); \
         if constexpr (DBG == 4) ++n_evt;                                                                                 \
       }
 #define S5_PAIRS(EXF)                                                                                                    \
@@ -620,6 +707,11 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     if constexpr (DBG == 3) t_ladder += __builtin_amdgcn_s_memtime() - t_mid;
     if (tl == next_rf) {
       // every later item has a larger index than the k buffered items at or above the bound: it needs a strictly larger score
+      if constexpr (CML) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ds_max updates have been performed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[r] = *(volatile __attribute__((address_space(3))) float*)(size_t)(cm_addr + r * 256);
+      }
       const float tk = s5_kth_of_32(cm, k);
       thr = tk > thr ? tk : thr;
       const int gap = (tl + 2) >> 1;
@@ -925,7 +1017,7 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
     const int rc = s5_build_events(ev_buf, ev_bytes, Bu, I, u_idx, eptr, eidx, excl_nnz, item_offset, 32 * NJ, build_events != 0, &evs, s);
     if (rc) return rc;
   }
-  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + 2 * NS * 4 + 16;
+  const size_t lds = (size_t)NS * (32 * NJ) * KS * 32 + 2 * NS * 4 + 16 + (KS >= S5_CML_KS ? (size_t)S5_MAXW * 4096 : 0);      // + the class maxima of D = 256
   SBR_REQUIRE(lds <= 160 * 1024, "sbr_score_topk_f16: LDS budget exceeded (%zu bytes)", lds);
   // prefix pass (class maxima only, no appends) over the first S5_PRE_TILES tiles: its bound spares the main pass the appends of its
   // first tiles (every score passes a threshold of -inf), at the price of scoring those tiles twice (measured on c2: 0 tiles 1.76 ms,
