@@ -219,7 +219,8 @@ def gemm_kernel(mode, M, N, K, gathered):
 
 PMC_SCORER_PREFIX = '_Z23score_topk_f16_n_kernel'        # fused scorer dispatches in the same PMC passes (the only launches of that kernel there)
 # entry point -> kernel symbol of the kernel trace / PMC summaries, for the kernels that are no GEMMs
-ENTRY_KERNEL = {'sbr_adam_step_zero_grad': 'void adamw_kernel<true>', 'sbr_adam_step': 'void adamw_kernel<false>'}
+ENTRY_KERNEL = {'sbr_adam_step_zero_grad': 'void adamw_kernel<true>', 'sbr_adam_step': 'void adamw_kernel<false>',
+                'sbr_adam_step_rows': 'adam_step_rows_kernel'}
 
 
 def csrc_sha16():
@@ -337,7 +338,7 @@ def dominant_gemm(timings, steps, batch=None):
     return out
 
 
-def step_roofline(timings, steps, batch, n_params):
+def step_roofline(timings, steps, batch, n_params, deferred_table=0, table_dim=0):
     """The ``roofline`` object of the line: the kernel with the largest time per step over ALL kernels of the step (GEMM signatures
     and every other entry point), priced on the resource that bounds it; the largest GEMM rides along as ``dominant_gemm``."""
     gemm = dominant_gemm(timings, steps, batch)
@@ -349,16 +350,18 @@ def step_roofline(timings, steps, batch, n_params):
     if other and (gemm is None or other[0]['ms_per_step'] > gemm['kernel_ms_per_step']):
         top = other[0]
         name = top['entry_point']
-        if name in ('sbr_adam_step_zero_grad', 'sbr_adam_step') and n_params:
+        if name in ('sbr_adam_step_zero_grad', 'sbr_adam_step', 'sbr_adam_step_rows') and n_params:
             # dense AdamW (train/trainer.py:62-68 -> optimizer.step(), zero_grad()): reads p, g, m, v and writes p, m, v = 28 bytes per
-            # parameter (the gradient reset only writes elements that are not +0 already)
-            byts = 28.0 * n_params
+            # parameter (the gradient reset only writes elements that are not +0 already). With the lookup user table updated row by
+            # row (sbr_adam_step_rows) only the rows of the batch are touched: 28 bytes per element of at most `batch` rows.
+            byts = 28.0 * n_params if name != 'sbr_adam_step_rows' else 28.0 * (n_params - deferred_table + min(batch * table_dim, deferred_table))
             t = top['avg_launch_ms'] * 1e-3
             traffic, note = pmc_symbol_traffic(ENTRY_KERNEL.get(name), batch)
             out = {'bound': 'hbm', 'achieved': round(byts / t / 1e9, 1), 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': round(byts / t / 1e9 / PEAK_HBM, 4),
                    'traffic': traffic, 'traffic_source': note, 'algorithmic_bytes': byts,
-                   'kernel': f'{ENTRY_KERNEL.get(name)} ({name}): dense AdamW over all {n_params} parameters + gradient reset + loss read-out, '
-                             f'28 bytes per parameter', 'avg_launch_ms': top['avg_launch_ms'], 'kernel_ms_per_step': top['ms_per_step'],
+                   'kernel': f'{ENTRY_KERNEL.get(name)} ({name}): AdamW step + gradient reset + loss read-out over {n_params} parameters' +
+                             (f' ({deferred_table} of them a lookup table updated row by row: only the batch\'s rows are touched)' if name == 'sbr_adam_step_rows' else '') +
+                             ', 28 bytes per touched parameter', 'avg_launch_ms': top['avg_launch_ms'], 'kernel_ms_per_step': top['ms_per_step'],
                    'timing': TIMING_NOTE}
     if out is None:
         out = dict(gemm) if gemm else None
@@ -847,7 +850,8 @@ def main():
             out['config']['param_checksum'] = [float(c) for c in chk]
             out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
     n_params = sum(p.numel() for p in net.parameters())
-    roof = step_roofline(timings, args.steps, args.batch_size, n_params) if rank == 0 else None
+    utab = net.user_embedding_module.embedding_layer.weight
+    roof = step_roofline(timings, args.steps, args.batch_size, n_params, utab.numel(), utab.shape[1]) if rank == 0 else None
     if roof:
         out['roofline'] = roof
     if not args.no_b256:

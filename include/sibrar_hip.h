@@ -355,10 +355,17 @@ int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, lo
  * every step; a row without gradient can take its zero-gradient updates later, in order, bit-identically). mode 0: bring the rows
  * named by ids (int64 or int32, optionally through rowmap) up to step - 1 (before the forward pass reads them); mode 1: the same,
  * then apply `step` with their gradient rows, zero those gradient rows, record the step's scalars in sched[step]; mode 2: flush
- * every row to `step` (before any other reader). claim, last: int32 [n_rows] zero-initialised; sched: float2 [> step]. */
+ * every row to `step` (before any other reader). claim, last: int32 [n_rows * ceil(D / 64)] (one entry per 64-element sub-row, the
+ * work of one wave), zero-initialised; sched: float2 [> step]. */
 int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64, const int* ids32,
                   const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1, double b2, double eps,
                   double wd, long step, void* stream);
+/* optimizer.step() + zero_grad() of a step whose flat buffers (n elements) hold ONE deferred table in [lo, hi): mode 1 of
+ * sbr_adam_rows for the table's rows named by ids and sbr_adam_step_zero_grad for every other element, in one launch; rows of the
+ * table that received no gradient are not touched (new in ABI 3). */
+int sbr_adam_step_rows(int kind, float* p, float* g, float* m, float* v, long n, long lo, long hi, int D, const long* ids64,
+                       const int* ids32, const int* rowmap, long n_ids, int* claim, int* last, void* sched, double lr, double b1,
+                       double b2, double eps, double wd, long step, const double* copy_src, double* copy_dst, int copy_n, void* stream);
 int sbr_adagrad_step(float* p, const float* g, float* state_sum, long n, double lr, double eps, double wd, void* stream);
 
 /* ---- full-catalogue evaluation — eval/eval.py:205-222 ------------------------------------------------------------------------

@@ -53,79 +53,137 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
 
 // ---- deferred row-wise Adam for lookup tables --------------------------------------------------------------------------------
 // The reference's dense optimizer (trainer.py:62-68) updates EVERY row of an embedding table EVERY step — rows without a
-// gradient still decay their moments and their weights — which makes the optimizer the largest kernel of the step for large
-// tables (c4: 7.2 GB of state per step). A row that gets no gradient at steps s0+1 .. t-1 can take those updates later, in
-// order, with g = 0: the arithmetic is the same sequence of fp32 operations, so the result is bit-identical to the dense
-// optimizer's. State per table: last[r] = step up to which row r is current; sched[s] = (lr / bc1(s), sqrt(bc2(s))) of every
-// step so far (evaluated on the host in double as for the dense kernel). A step brings the rows its batch READS up to t-1
-// before the forward pass (catch-up), updates the rows that RECEIVED gradient with step t after the backward pass, and a
-// flush replays everything before any other reader (evaluation, state_dict, checkpoints) looks at the table.
-// Duplicate rows in a batch: the first wave to raise claim[r] to the launch's token owns the row.
+// gradient still decay their moments and their weights — which makes the optimizer the largest kernel of the step (c2: 358 of its
+// 541 MB per step are the user table, of whose rows a batch touches 8 %; c4: 7.2 GB of state per step). A row that gets no
+// gradient at steps s0+1 .. t-1 can take those updates later, in order, with g = 0: the arithmetic is the same sequence of fp32
+// operations, so the result is bit-identical to the dense optimizer's. State per table, per SUB-ROW (64 consecutive elements of a
+// row = the work of one wave; a row of D elements has ceil(D / 64) of them): last[q] = step up to which sub-row q is current;
+// sched[s] = (lr / bc1(s), sqrt(bc2(s))) of every step so far (evaluated on the host in double as for the dense kernel). A step
+// brings the rows its batch READS up to t-1 before the forward pass (catch-up), updates the rows that RECEIVED gradient with step t
+// after the backward pass (inside the dense launch of the other parameters: sbr_adam_step_rows), and a flush replays everything
+// before any other reader (evaluation, state_dict, checkpoints) looks at the table.
+// Duplicate rows in a batch: the first wave to raise claim[q] to the launch's token owns the sub-row.
+// The replay is a dependent chain per element; what made the first version slow (52 us for 8,192 rows) was not its arithmetic but
+// one L2 round trip per replayed step for sched[s]: a wave now fetches the schedule of up to 64 steps with ONE load (lane i holds
+// step s0 + 1 + i) and broadcasts an entry per step with v_readlane; the loop is unrolled by four so that the square roots and
+// divisions of neighbouring steps (which depend on the moments only, not on the parameter) overlap.
 __device__ __forceinline__ void adam_replay(float& pe, float& me, float& ve, int s_from, int s_to, const float2* __restrict__ sched,
-                                            const AdamHyper& h, float zero) {
-  for (int s = s_from; s <= s_to; ++s) {
-    const float2 sc = sched[s];
-    adam_element(pe, zero, me, ve, h, sc.x, sc.y);
+                                            const AdamHyper& h, float zero, int lane) {
+  for (int base = s_from; base <= s_to; base += 64) {                 // s_from / s_to are wave-uniform
+    const int cnt = s_to - base + 1 < 64 ? s_to - base + 1 : 64;
+    const float2 mine = lane < cnt ? sched[base + lane] : make_float2(1.f, 1.f);
+    const int sx = __float_as_int(mine.x), sy = __float_as_int(mine.y);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        adam_element(pe, zero, me, ve, h, __int_as_float(__builtin_amdgcn_readlane(sx, i + q)), __int_as_float(__builtin_amdgcn_readlane(sy, i + q)));
+    }
+    for (; i < cnt; ++i)
+      adam_element(pe, zero, me, ve, h, __int_as_float(__builtin_amdgcn_readlane(sx, i)), __int_as_float(__builtin_amdgcn_readlane(sy, i)));
   }
 }
 
-// mode 0: catch-up of the rows ids[j] (mapped through rowmap when given) to step t - 1.
-// mode 1: catch-up to t - 1, then step t with the gradient row; the gradient row is zeroed; sched[t] is recorded.
+// One wave = one sub-row (64 elements) of one row named by ids[j]. mode 0: catch-up to step t - 1. mode 1: catch-up to t - 1, then
+// step t with the gradient, which is zeroed.
+__device__ __forceinline__ void adam_subrow(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int D,
+                                            int n_sub, const long* __restrict__ ids64, const int* __restrict__ ids32,
+                                            const int* __restrict__ rowmap, long w, int* __restrict__ claim, int* __restrict__ last,
+                                            const float2* __restrict__ sched, int t, const AdamHyper& h, float step_size, float bc2_sqrt,
+                                            float zero, int mode, int lane) {
+  const long j = w / n_sub;
+  const int sub = (int)(w - j * n_sub);
+  const long id = ids64 ? ids64[j] : (long)ids32[j];
+  const int r = rowmap ? rowmap[id] : (int)id;
+  if (r < 0) return;                                          // id without a row: flagged by the lookup kernel
+  const long q = (long)r * n_sub + sub;
+  const int token = 2 * t - 1 + mode;
+  int old = 0;
+  if (lane == 0) old = atomicMax(&claim[q], token);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old >= token) return;                                   // another wave of this launch owns the sub-row
+  const int s0 = __builtin_amdgcn_readfirstlane(last[q]);
+  const int c = sub * 64 + lane;
+  const long e = (long)r * D + (c < D ? c : D - 1);
+  float pe = p[e], me = m[e], ve = v[e];
+  adam_replay(pe, me, ve, s0 + 1, t - 1, sched, h, zero, lane);
+  if (mode == 1) adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
+  if (c < D) {
+    p[e] = pe;
+    m[e] = me;
+    v[e] = ve;
+    if (mode == 1) g[e] = 0.f;
+  }
+  if (lane == 0) last[q] = mode == 1 ? t : t - 1;
+}
+
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, int D, const long* __restrict__ ids64,
+                                                        float* __restrict__ v, int D, int n_sub, const long* __restrict__ ids64,
                                                         const int* __restrict__ ids32, const int* __restrict__ rowmap, long n,
                                                         int* __restrict__ claim, int* __restrict__ last,
                                                         float2* __restrict__ sched, int t, AdamHyper h, float step_size,
                                                         float bc2_sqrt, const float* __restrict__ zero_src, int mode) {
-  const long j = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const long w = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) sched[t] = make_float2(step_size, bc2_sqrt);
-  if (j >= n) return;
-  long id = ids64 ? ids64[j] : (long)ids32[j];
-  const int r = rowmap ? rowmap[id] : (int)id;
-  if (r < 0) return;                                          // id without a row: flagged by the lookup kernel
-  const int token = 2 * t - 1 + mode;
-  int old = 0;
-  if (lane == 0) old = atomicMax(&claim[r], token);
-  old = __shfl(old, 0, 64);
-  if (old >= token) return;                                   // another wave of this launch owns the row
-  const int s0 = last[r];
-  const float zero = zero_src[0];
-  for (int c = lane; c < D; c += 64) {
-    const long e = (long)r * D + c;
-    float pe = p[e], me = m[e], ve = v[e];
-    adam_replay(pe, me, ve, s0 + 1, t - 1, sched, h, zero);
-    if (mode == 1) {
-      adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
-      g[e] = 0.f;
-    }
-    p[e] = pe;
-    m[e] = me;
-    v[e] = ve;
-  }
-  if (lane == 0) last[r] = mode == 1 ? t : t - 1;
+  if (w >= n * n_sub) return;
+  adam_subrow(p, g, m, v, D, n_sub, ids64, ids32, rowmap, w, claim, last, sched, t, h, step_size, bc2_sqrt, zero_src[0], mode, threadIdx.x & 63);
 }
 
-// every row of the table up to step t (before another reader looks at the table)
+// every sub-row of the table up to step t (before another reader looks at the table)
 __global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                              int D, long n_rows, int* __restrict__ last,
+                                                              int D, int n_sub, long n_rows, int* __restrict__ last,
                                                               const float2* __restrict__ sched, int t, AdamHyper h,
                                                               const float* __restrict__ zero_src) {
-  const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (r >= n_rows) return;
+  const long q = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= n_rows * n_sub) return;
   const int lane = threadIdx.x & 63;
-  const int s0 = last[r];
+  const int s0 = __builtin_amdgcn_readfirstlane(last[q]);
   if (s0 >= t) return;
-  const float zero = zero_src[0];
-  for (int c = lane; c < D; c += 64) {
-    const long e = r * D + c;
-    float pe = p[e], me = m[e], ve = v[e];
-    adam_replay(pe, me, ve, s0 + 1, t, sched, h, zero);
+  const long r = q / n_sub;
+  const int c = (int)(q - r * n_sub) * 64 + lane;
+  const long e = r * D + (c < D ? c : D - 1);
+  float pe = p[e], me = m[e], ve = v[e];
+  adam_replay(pe, me, ve, s0 + 1, t, sched, h, zero_src[0], lane);
+  if (c < D) {
     p[e] = pe;
     m[e] = me;
     v[e] = ve;
   }
-  if (lane == 0) last[r] = t;
+  if (lane == 0) last[q] = t;
+}
+
+// The optimizer launch of a step whose flat buffers hold one deferred table in [lo, hi): workgroups [0, row_blocks) apply step t to
+// the sub-rows that received gradient (mode 1 of adam_subrow, four waves each), the rest run the dense kernel (with the gradient
+// reset and the loss read-out of adamw_kernel<true>) over [0, lo) and [hi, n): ONE launch for optimizer.step() + zero_grad().
+__global__ __launch_bounds__(256) void adam_step_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, long n, long lo, long hi, int D, int n_sub,
+                                                             const long* __restrict__ ids64, const int* __restrict__ ids32,
+                                                             const int* __restrict__ rowmap, long n_ids, int* __restrict__ claim,
+                                                             int* __restrict__ last, float2* __restrict__ sched, int t, AdamHyper h,
+                                                             float step_size, float bc2_sqrt, const float* __restrict__ zero_src,
+                                                             int row_blocks, const double* __restrict__ cp_src, double* __restrict__ cp_dst,
+                                                             int cp_n) {
+  if ((int)blockIdx.x < row_blocks) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sched[t] = make_float2(step_size, bc2_sqrt);
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (w < n_ids * n_sub)
+      adam_subrow(p + lo, g + lo, m + lo, v + lo, D, n_sub, ids64, ids32, rowmap, w, claim, last, sched, t, h, step_size, bc2_sqrt, zero_src[0], 1,
+                  threadIdx.x & 63);
+    return;
+  }
+  const long b = blockIdx.x - row_blocks, nb = gridDim.x - row_blocks;
+  if (b == 0 && (int)threadIdx.x < cp_n) cp_dst[threadIdx.x] = cp_src[threadIdx.x];
+  const long span = hi - lo, n_dense = n - span;
+  for (long d = b * (long)blockDim.x + threadIdx.x; d < n_dense; d += nb * blockDim.x) {
+    const long e = d < lo ? d : d + span;
+    float pe = p[e], me = m[e], ve = v[e];
+    const float ge = g[e];
+    adam_element(pe, ge, me, ve, h, step_size, bc2_sqrt);
+    p[e] = pe;
+    m[e] = me;
+    v[e] = ve;
+    if (__float_as_uint(ge) != 0u) g[e] = 0.f;
+  }
 }
 
 __device__ float sbr_adam_zero = 0.f;
@@ -180,16 +238,17 @@ extern "C" int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, f
   return SBR_OK;
 }
 
-// Deferred row-wise Adam / AdamW over one [n_rows, D] lookup table (see adam_rows_kernel). mode 0: bring the rows named by
+// Deferred row-wise Adam / AdamW over one [n_rows, D] lookup table (see adam_subrow). mode 0: bring the rows named by
 // ids (int64 ids64 or int32 ids32, optionally mapped through rowmap) up to step - 1; mode 1: the same, then apply `step` with
 // their gradient rows, zero those gradient rows and record the step's scalars in sched[step]; mode 2: flush all rows to `step`.
-// claim / last: int32 [n_rows], zero-initialised by the caller; sched: float2 [>= step + 1].
+// claim / last: int32 [n_rows * ceil(D / 64)] (one entry per 64-element sub-row), zero-initialised by the caller;
+// sched: float2 [>= step + 1].
 extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64,
                              const int* ids32, const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1,
                              double b2, double eps, double wd, long step, void* stream) {
   SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_rows: unknown kind %d", kind);
   SBR_REQUIRE(mode >= 0 && mode <= 2, "sbr_adam_rows: unknown mode %d", mode);
-  SBR_REQUIRE(p && m && v && last && sched, "sbr_adam_rows: null operand");
+  SBR_REQUIRE(p && m && v && last && sched && D >= 1, "sbr_adam_rows: null operand");
   SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_rows: step %ld out of range", step);
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
   float* zero = nullptr;
@@ -198,9 +257,10 @@ extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, f
     return SBR_ERR_HIP;
   }
   hipStream_t s = (hipStream_t)stream;
+  const int n_sub = (D + 63) / 64;
   if (mode == 2) {
     if (n_rows == 0) return SBR_OK;
-    adam_rows_flush_kernel<<<sbr_cdiv(n_rows, 4), 256, 0, s>>>(p, m, v, D, n_rows, last, (const float2*)sched, (int)step, h, zero);
+    adam_rows_flush_kernel<<<sbr_cdiv(n_rows * n_sub, 4), 256, 0, s>>>(p, m, v, D, n_sub, n_rows, last, (const float2*)sched, (int)step, h, zero);
     SBR_CHECK_LAUNCH("sbr_adam_rows (flush)");
     return SBR_OK;
   }
@@ -208,10 +268,40 @@ extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, f
   SBR_REQUIRE(mode == 0 || g, "sbr_adam_rows: the update needs the gradient");
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  const long blocks = n > 0 ? sbr_cdiv(n, 4) : 1;           // mode 1 with no rows still records sched[step]
-  adam_rows_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, D, ids64, ids32, rowmap, n, claim, last, (float2*)sched, (int)step, h,
+  const long blocks = n > 0 ? sbr_cdiv(n * n_sub, 4) : 1;     // mode 1 with no rows still records sched[step]
+  adam_rows_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, D, n_sub, ids64, ids32, rowmap, n, claim, last, (float2*)sched, (int)step, h,
                                           (float)(lr / bc1), (float)sqrt(bc2), zero, mode);
   SBR_CHECK_LAUNCH("sbr_adam_rows");
+  return SBR_OK;
+}
+
+// optimizer.step() + zero_grad() of a step with ONE deferred table in one launch: the flat buffers p / g / m / v of n elements hold
+// the table in [lo, hi) (hi - lo = n_rows * D); its rows named by ids get mode 1 of sbr_adam_rows, every other element the dense step
+// of sbr_adam_step_zero_grad (gradient reset, copy_n doubles copy_src -> copy_dst). Untouched rows of the table are not read.
+extern "C" int sbr_adam_step_rows(int kind, float* p, float* g, float* m, float* v, long n, long lo, long hi, int D, const long* ids64,
+                                  const int* ids32, const int* rowmap, long n_ids, int* claim, int* last, void* sched, double lr,
+                                  double b1, double b2, double eps, double wd, long step, const double* copy_src, double* copy_dst,
+                                  int copy_n, void* stream) {
+  SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_step_rows: unknown kind %d", kind);
+  SBR_REQUIRE(p && g && m && v && claim && last && sched && (ids64 || ids32 || n_ids == 0), "sbr_adam_step_rows: null operand");
+  SBR_REQUIRE(0 <= lo && lo <= hi && hi <= n && D >= 1 && (hi - lo) % D == 0, "sbr_adam_step_rows: bad table range [%ld, %ld) of %ld, D = %d", lo, hi, n, D);
+  SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_step_rows: step %ld out of range", step);
+  SBR_REQUIRE(copy_n >= 0 && copy_n <= 256 && (copy_n == 0 || (copy_src && copy_dst)), "sbr_adam_step_rows: bad copy request");
+  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
+  float* zero = nullptr;
+  if (hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(sbr_adam_zero)) != hipSuccess) {
+    sbr_set_error("sbr_adam_step_rows: hipGetSymbolAddress failed");
+    return SBR_ERR_HIP;
+  }
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  const int n_sub = (D + 63) / 64;
+  const int row_blocks = n_ids > 0 ? sbr_cdiv(n_ids * n_sub, 4) : 1;       // block 0 records sched[step] even without rows
+  const int dense_blocks = grid_for(n - (hi - lo));
+  adam_step_rows_kernel<<<row_blocks + dense_blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lo, hi, D, n_sub, ids64, ids32, rowmap, n_ids, claim,
+                                                                                    last, (float2*)sched, (int)step, h, (float)(lr / bc1),
+                                                                                    (float)sqrt(bc2), zero, row_blocks, copy_src, copy_dst, copy_n);
+  SBR_CHECK_LAUNCH("sbr_adam_step_rows");
   return SBR_OK;
 }
 

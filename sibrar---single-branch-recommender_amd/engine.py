@@ -468,10 +468,11 @@ class _PlainRun:
 
 
 class DeferredTable:
-    """Deferred row-wise Adam / AdamW for ONE lookup table (``sbr_adam_rows``; csrc/optim.hip explains why the result is
-    bit-identical to the dense optimizer of train/trainer.py:62-68). ``catch_up`` before the forward pass of a step, ``update``
-    after its backward pass, ``flush`` before anybody else reads the table: the model's state_dict, its module-level forward
-    (evaluation, autograd path), a dense optimizer step, ``FusedTrainStep.close``."""
+    """Deferred row-wise Adam / AdamW for ONE lookup table (``sbr_adam_rows`` / ``sbr_adam_step_rows``; csrc/optim.hip explains why
+    the result is bit-identical to the dense optimizer of train/trainer.py:62-68). ``catch_up`` before the forward pass of a step,
+    ``step`` = the step's whole optimizer launch (row updates of this table + the dense step of every other parameter),
+    ``flush`` before anybody else reads the table: the model's state_dict, its module-level forward (evaluation, autograd path), a
+    dense optimizer step, ``FusedTrainStep.close``."""
 
     def __init__(self, opt, param: torch.Tensor, lo: int, hi: int, rowmap: Optional[torch.Tensor]):
         n_rows, D = param.shape
@@ -481,8 +482,9 @@ class DeferredTable:
         self.p, self.g = fp.flat[lo:hi], fp.grad[lo:hi]
         self.m, self.v = opt.m[lo:hi], opt.v[lo:hi]
         dev = self.p.device
-        self.last = torch.zeros(n_rows, device=dev, dtype=torch.int32)
-        self.claim = torch.zeros(n_rows, device=dev, dtype=torch.int32)
+        n_sub = (D + 63) // 64                   # one bookkeeping entry per 64-element sub-row (the work of one wave)
+        self.last = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
+        self.claim = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
         self.sched = torch.zeros(4096, 2, device=dev, dtype=torch.float32)
         self.kind = 0 if opt.name == 'adamw' else 1
         self.flushed_to = 0          # step up to which EVERY row is known to be current
@@ -490,13 +492,21 @@ class DeferredTable:
             self.last.fill_(opt.step_count)
             self.flushed_to = opt.step_count
 
-    def _call(self, mode: int, ids, step: int):
+    def _grow_sched(self, step: int):
         if step >= self.sched.shape[0]:
             bigger = torch.zeros(2 * max(step, self.sched.shape[0]), 2, device=self.sched.device, dtype=torch.float32)
             bigger[:self.sched.shape[0]] = self.sched
             self.sched = bigger
+
+    @staticmethod
+    def _ids(ids):
         ids64 = ids if ids is not None and ids.dtype == torch.int64 else None
         ids32 = ids if ids is not None and ids.dtype == torch.int32 else None
+        return ids64, ids32
+
+    def _call(self, mode: int, ids, step: int):
+        self._grow_sched(step)
+        ids64, ids32 = self._ids(ids)
         o = self.opt
         call('sbr_adam_rows', self.kind, mode, ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.n_rows, self.D, ptr(ids64),
              ptr(ids32), ptr(self.rowmap) if ids64 is not None else None, 0 if ids is None else ids.numel(), ptr(self.claim),
@@ -508,8 +518,24 @@ class DeferredTable:
             self._call(0, ids, self.opt.step_count + 1)
 
     def update(self, ids: torch.Tensor):
-        """Apply step ``opt.step_count`` (already counted by step_flat) to the rows that received gradient; zeroes those rows."""
+        """Apply step ``opt.step_count`` (already counted) to the rows that received gradient; zeroes those gradient rows."""
         self._call(1, ids, self.opt.step_count)
+
+    def step(self, ids: torch.Tensor, copy=None) -> bool:
+        """The optimizer launch of a step (optimizer.step() + zero_grad() of train/trainer.py:221-222): this table's rows named by
+        ``ids`` take the step with their gradient rows, every other parameter of the flat buffer takes the dense step, consumed
+        gradient elements are reset, ``copy`` = (src, dst) float64 tensors ride along. Returns True when ``copy`` was made."""
+        o = self.opt
+        o.step_count += 1
+        self._grow_sched(o.step_count)
+        ids64, ids32 = self._ids(ids)
+        src, dst = copy if copy is not None else (None, None)
+        fp = o.fp
+        call('sbr_adam_step_rows', self.kind, ptr(fp.flat), ptr(fp.grad), ptr(o.m), ptr(o.v), fp.total, self.lo, self.hi, self.D, ptr(ids64),
+             ptr(ids32), ptr(self.rowmap) if ids64 is not None else None, 0 if ids is None else ids.numel(), ptr(self.claim),
+             ptr(self.last), ptr(self.sched), float(o.lr), 0.9, 0.999, 1e-8, float(o.wd), int(o.step_count), ptr(src), ptr(dst),
+             0 if src is None else src.numel(), ops.stream())
+        return src is not None
 
     def flush(self):
         t = self.opt.step_count
@@ -574,15 +600,15 @@ class FusedTrainStep:
         self.opt.zero_grad()
         # lookup user table updated row by row instead of densely (DeferredTable). Needs to know which rows received
         # gradient: the batch's users on one GPU, the all-gathered row lists of the sparse exchange in a data-parallel run.
-        # OPT-IN (SBR_DEFERRED_ADAM=1): bit-identical, but measured no faster on c2 — the replay executes exactly the arithmetic
-        # the dense kernel hides under its HBM stream (c2, B = 8192: dense AdamW 82 -> 29 us, row kernels +74 us; at B = 256
-        # the four extra launches cost 0.1 ms of host time). It pays only where the table is far larger than what a step
-        # touches AND the replay loop is restructured for instruction-level parallelism.
+        # Bit-identical to the dense optimizer (tests/test_hip_kernels.py::test_deferred_row_wise_adam_replay_is_bit_identical);
+        # on by default (SBR_DEFERRED_ADAM=0: dense): the untouched rows of the table — 92 % of c2's user table at B = 8192, 99.7 %
+        # at the reference's batch 256 — leave the optimizer's HBM stream (c2: 358 of 541 MB per step). One extra launch per step
+        # (the catch-up of the rows a batch reads); the update rides on the optimizer launch (sbr_adam_step_rows).
         self.deferred = None
         fe = net.user_embedding_module
         if (isinstance(self.user, _PlainRun) and fe.kind == 'categorical' and self._urange is not None
                 and optimizer.name in ('adamw', 'adam') and optimizer.deferred is None
-                and os.environ.get('SBR_DEFERRED_ADAM', '0') == '1'
+                and os.environ.get('SBR_DEFERRED_ADAM', '1') != '0'
                 and (not parallel.is_distributed() or self._sparse is not False)):
             table = fe.front_params()[0]
             lo, hi = self._urange
@@ -883,23 +909,17 @@ class FusedTrainStep:
                 out = self._phase2().clone().unbind(0)
             # ---- reduce + update
             self._reduce_rest(pending)
-            if self.deferred is None:
-                # step() + zero_grad() in the optimizer's own launch — which also carries the step's loss scalars out of the
-                # captured step's static buffer into a fresh tensor (instead of a clone launch)
-                static = out if torch.is_tensor(out) else None
-                fresh = torch.empty_like(static) if static is not None else None
-                took = self.opt.step_flat(zero_grad=True, copy=(static, fresh) if static is not None else None)
-                if static is not None:
-                    self.last_out3 = fresh if took else static.clone()   # (total, rec, reg) of this step as one [3] tensor
-                    out = self.last_out3.unbind(0)
-            else:
-                if torch.is_tensor(out):
-                    out = out.clone().unbind(0)
-                d, g = self.deferred, self.opt.fp.grad
-                self.opt.step_flat(skip=(d.lo, d.hi))
-                d.update(self._touched_rows if self._sparse else pb.u[:-1])   # also re-zeroes the gradient rows it consumed
-                g[:d.lo].zero_()
-                g[d.hi:].zero_()
+            # step() + zero_grad() in the optimizer's own launch — which also carries the step's loss scalars out of the captured
+            # step's static buffer into a fresh tensor (instead of a clone launch)
+            static = out if torch.is_tensor(out) else None
+            fresh = torch.empty_like(static) if static is not None else None
+            cp = (static, fresh) if static is not None else None
+            # with a deferred lookup table the same launch updates it row by row: only the rows that received gradient are touched
+            rows = None if self.deferred is None else (self._touched_rows if self._sparse else pb.u[:-1])
+            took = self.opt.step_flat(zero_grad=True, copy=cp, rows=rows)
+            if static is not None:
+                self.last_out3 = fresh if took else static.clone()   # (total, rec, reg) of this step as one [3] tensor
+                out = self.last_out3.unbind(0)
             if native is not None:
                 native[0].release(native[1])                         # everything queued so far has read the slot
             return out

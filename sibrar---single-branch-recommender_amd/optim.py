@@ -91,12 +91,17 @@ class FusedOptimizer:
         self._sync_grads()
         self.step_flat()
 
-    def step_flat(self, skip=None, zero_grad: bool = False, copy=None):
+    def step_flat(self, skip=None, zero_grad: bool = False, copy=None, rows=None):
         """Update from the flat gradient buffer as it is (the fused step writes gradients there directly). ``zero_grad``: the
         gradient buffer is reset by the optimizer's own launch (Adam / AdamW; Adagrad zeroes it with a fill). ``copy`` = (src, dst)
         small float64 tensors: copied by that launch too (returns True when it was; Adam / AdamW with ``zero_grad`` only).
+        ``rows`` (with ``zero_grad``): ids / rows of the deferred table that received gradient -> one launch for everything.
         ``skip`` = (lo, hi): leave that range of the flat buffers alone — a lookup table whose rows the fused step updates
         itself, deferred row by row (engine.DeferredTable). A step without ``skip`` first brings such a table up to date."""
+        if rows is not None and self.deferred is not None and zero_grad and skip is None:
+            # ``rows``: the rows of the deferred lookup table that received gradient in this step — the table is updated row by
+            # row inside the same launch that steps every other parameter densely (engine.DeferredTable.step)
+            return self.deferred.step(rows, copy=copy)
         if skip is None and self.deferred is not None:
             self.deferred.flush()
         self.step_count += 1

@@ -498,8 +498,11 @@ def test_c2_step_at_the_bench_batch_against_the_cpu_oracle():
     fused.close()
 
 
-def test_c4_step_on_one_gpu_at_full_table_shapes():
-    """BASELINE configs[3] on ONE GPU (the 8-GPU job runs this per rank): 1M users x 200k items, text 768 + image 2048, C = D =
+@pytest.mark.parametrize('deferred', ['0', '1'])
+def test_c4_step_on_one_gpu_at_full_table_shapes(deferred, monkeypatch):
+    """(deferred = '1': the optimizer launch updates the 1M-row user table row by row — engine.DeferredTable, the default — and the
+    table is flushed before it is read; '0': one dense launch over all 257 M parameters.)
+    BASELINE configs[3] on ONE GPU (the 8-GPU job runs this per rank): 1M users x 200k items, text 768 + image 2048, C = D =
     256, user = embedding lookup (257 M parameters, 1 GB user table), sampled softmax, batch 256.
       * the fused step (plain launches, then capture + replay) against the module / autograd path over the same kernels, which
         the golden groups pin: loss and every gradient — all 257 M elements of the flat gradient buffer;
@@ -507,6 +510,7 @@ def test_c4_step_on_one_gpu_at_full_table_shapes():
         applied to that gradient — touched rows, a stride sample of untouched rows (pure weight decay) and two checksums of the
         whole user table."""
     from oracle import train_ref
+    monkeypatch.setenv('SBR_DEFERRED_ADAM', deferred)
     ds = S().SyntheticDataset(1_000_000, 200_000, 4_000_000, item_dense={'text': 768, 'image': 2048}, seed=0, n_negative_samples=10)
     cfg = {'shared_common_dim': 256, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
            'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'image'}], 'single_branch_hidden_layers': [256],
@@ -554,6 +558,8 @@ def test_c4_step_on_one_gpu_at_full_table_shapes():
     opts[1].step_flat = real_step
     p0 = {k_: v.detach().clone() for k_, v in nets[1].named_parameters()}
     fused.step(u, i, labels, draws)
+    assert (fused.deferred is not None) == (deferred == '1')
+    fused.flush()                                              # a row-wise updated table is brought up to date before it is read
     fp = opts[1].fp
     name_of = {id(p): k_ for k_, p in nets[1].named_parameters()}
     rows = torch.cat([u, torch.arange(0, 1_000_000, 9973)]).to(DEV)
