@@ -210,10 +210,12 @@ def gemm_kernel(mode, M, N, K, gathered):
             return (f'void gemm_split_tn_kernel<{"true" if (N // 128) * (M // 128) > 1 else "false"}>', 'bf16-split dW kernel (csrc/gemm_split_tn_f32.hip)', 6, 'bf16')
         return ('void gemm_ring_kernel<1, true, true, 2>', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
     if split and M >= getattr(ops, '_SPLIT_MIN_ROWS', 4096):
-        if mode == 0 and gathered and lib.sbr_gemm_split_proj_supported(int(M), int(N), int(K)):
-            return ('gemm_split_proj_kernel', 'bf16-split projector kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
-        if lib.sbr_gemm_split_supported(int(M), int(N), int(K)):
+        if lib.sbr_gemm_split_supported(int(M), int(N), int(K)) and not gathered:
             return (f'void gemm_split_kernel<{mode}, ', 'bf16-split shared-MLP kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
+        if mode == 0 and lib.sbr_gemm_split_proj_supported(int(M), int(N), int(K)):
+            return ('gemm_split_proj_kernel', 'bf16-split projector kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
+        if lib.sbr_gemm_split_wide_supported(int(M), int(N), int(K)):
+            return ('gemm_split_wide_kernel', 'wide bf16-split kernel (csrc/gemm_split_wide_f32.hip)', 6, 'bf16')
     return ('void gemm_ring_kernel<', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
 
 

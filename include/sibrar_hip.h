@@ -57,6 +57,12 @@ int sbr_gemm_nt_splitk_f32(const float* A, long lda, const int* a_idx, const flo
                            long ldc, const int* c_idx, int M, int N, int K, int act, void* workspace, long workspace_bytes,
                            void* stream);
 
+/* The same fp32 products for WIDE layers on the bf16 matrix pipe (csrc/gemm_split_wide_f32.hip; new in ABI 3): N a multiple of 256,
+ * K a multiple of 32 of at least 64 — modules/polylinear.py:51 with hidden widths 256 / 512, forward (mode 0, NT: W [N][K]) and input
+ * gradient (mode 1, NN: W [K][N]): C[ci(m), :] = act(A[ai(m), :] x W (+ bias)). a_idx / c_idx / bias may be NULL. */
+int sbr_gemm_split_wide_supported(long M, int N, int K);
+int sbr_gemm_split_wide_f32(int mode, const float* A, long lda, const int* a_idx, const float* W, long ldw, const float* bias, float* C,
+                            long ldc, const int* c_idx, long M, int N, int K, int act, void* stream);
 /* TN with a deterministic split-K slab reducer (no atomics): C[m, n] = sum_k A[ak(k), m] * B[bk(k), n], C overwritten.
  * autograd of nn.Linear w.r.t. its weight (dW = dZ^T X[rows]). workspace: sbr_gemm_tn_f32_workspace(M, N, K) bytes. */
 long sbr_gemm_tn_f32_workspace(int M, int N, int K);

@@ -102,6 +102,7 @@ _WRES = True                    # weights-resident kernel for N = K = 128 produc
 # the fp32 pipe (v_mfma_f32_32x32x2_f32)
 _SPLIT = _os.environ.get('SBR_GEMM_SPLIT', '1') != '0'
 _SPLIT_MIN_ROWS = 4096          # below this the per-workgroup weight set-up is not amortised
+_WIDE_HEURISTIC = True          # tests switch it off to reach the wide kernel at small shapes
 
 
 def _mlp_kernel(M, N, K) -> str:
@@ -117,6 +118,19 @@ def _wres_ok(M, N, K, *tensors) -> bool:
     if not _WRES or M < 1 or not lib().sbr_gemm_wres_supported(int(M), int(N), int(K)):
         return False
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
+
+
+def _wide_ok(M, N, K, a, w, out, nt: bool) -> bool:
+    """The wide bf16-split kernel (csrc/gemm_split_wide_f32.hip) takes the product: enough rows, N = 256 i, K = 32 j >= 64, 16-byte
+    aligned rows of A (and of W for NT), unit column strides."""
+    if not _SPLIT or M < _SPLIT_MIN_ROWS or not lib().sbr_gemm_split_wide_supported(int(M), int(N), int(K)):
+        return False
+    # where it pays (measured against the fp32 ring kernel, tools/lab/wide_time.py): enough 256 x 256 tiles to fill the chip's 256
+    # workgroup slots, and a wide or deep product (256 x 256 layers run as fast on the fp32 pipe)
+    if _WIDE_HEURISTIC and (-(-M // 256) * (N // 256) < 176 or max(N, K) < 512):
+        return False
+    ok = a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    return ok and (not nt or (w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0))
 
 
 def linear_nt_stats_ok(x, W, out) -> bool:
@@ -162,6 +176,12 @@ def linear_nt(x, W, bias=None, act=0, a_idx=None, out=None, c_idx=None, n_rows=N
                lambda: call('sbr_gemm_split_proj_f32', ptr(x), x.stride(0), ptr(a_idx), ptr(W), W.stride(0), ptr(bias), ptr(out),
                             out.stride(0), ptr(c_idx), M, N, K, act, stream()))
         return out
+    if _wide_ok(M, N, K, x, W, out, nt=True):
+        # wide layers (N = 256 i: hidden widths 256 / 512, the projectors of C = 256 / 512) on the bf16 matrix pipe, gather and scatter fused
+        _timed(('gemm_f32', 0, M, N, K, a_idx is not None),
+               lambda: call('sbr_gemm_split_wide_f32', 0, ptr(x), x.stride(0), ptr(a_idx), ptr(W), W.stride(0), ptr(bias), ptr(out),
+                            out.stride(0), ptr(c_idx), M, N, K, act, stream()))
+        return out
     ws_bytes = lib().sbr_gemm_nt_splitk_workspace(M, N, K) if M > 0 else 0
     if ws_bytes > 0:
         # few output tiles, long K (the modality projectors at small batches): K split over workgroups, deterministic reduce
@@ -184,6 +204,11 @@ def matmul_nn(dz, W, a_idx=None, n_rows=None, out=None):
         _timed(('gemm_f32', 1, M, N, K, False),
                lambda: call(_mlp_kernel(M, N, K), 1, ptr(dz), dz.stride(0), ptr(W), W.stride(0), None, ptr(out), out.stride(0), M, N, K, 0,
                             None, 0, None, stream()))
+        return out
+    if _wide_ok(M, N, K, dz, W, out, nt=False):
+        _timed(('gemm_f32', 1, M, N, K, a_idx is not None),
+               lambda: call('sbr_gemm_split_wide_f32', 1, ptr(dz), dz.stride(0), ptr(a_idx), ptr(W), W.stride(0), None, ptr(out),
+                            out.stride(0), None, M, N, K, 0, stream()))
         return out
     gemm(1, dz, dz.stride(0), a_idx, W, W.stride(0), None, None, out, out.stride(0), None, M, N, K, 0, 0)
     return out

@@ -13,6 +13,22 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+import importlib as _importlib
+
+
+class _LibProxy:
+    """tests set _lib.CALL_LOG on the package's _lib module (resolved lazily: the package name is not an identifier)"""
+    def _m(self):
+        return _importlib.import_module('sibrar---single-branch-recommender_amd._lib')
+    def __getattr__(self, k):
+        return getattr(self._m(), k)
+    def __setattr__(self, k, v):
+        setattr(self._m(), k, v)
+
+
+_lib = _LibProxy()
+
+
 def S():
     import sibrar_amd
     return sibrar_amd
@@ -814,6 +830,61 @@ def test_split_gemm_has_the_error_of_the_fp32_pipe(M, monkeypatch):
     assert torch.equal(out == 0, (y_act <= 0) | (out == 0))
     close(db.cpu(), out.double().sum(0).cpu(), rtol=1e-5, atol=1e-5, what='folded bias gradient', norm_rtol=1e-6)
     assert float(ws.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,mode,gather', [(4096, 256, 64, 0, ''), (5000, 512, 512, 0, ''), (9001, 256, 1024, 0, 'ac'), (30805, 512, 1024, 0, 'ac'),
+                                               (4097, 256, 128, 1, ''), (9001, 512, 256, 1, ''), (70001, 512, 512, 1, ''), (4100, 768, 96, 0, 'c')])
+def test_wide_split_gemm_has_the_error_of_the_fp32_pipe(M, N, K, mode, gather, monkeypatch):
+    """sbr_gemm_split_wide_f32 (N = 256 i, K = 32 j: the hidden layers and projectors of the C = 256 / 512 configurations on the bf16
+    matrix pipe — three-way exact operand splits, six MFMA terms, fp32 accumulate; csrc/gemm_split_wide_f32.hip) through
+    ops.linear_nt (mode 0, bias + ReLU, row gather and row scatter fused) and ops.matmul_nn (mode 1) against an fp64 product: error
+    of the size of the fp32-pipe kernel's own, on operands spanning six decades; ragged last row group, several tiles per workgroup."""
+    ops = S().ops
+    monkeypatch.setattr(ops, '_WIDE_HEURISTIC', False)
+    g = torch.Generator().manual_seed(M + N + K)
+    rows = M if 'a' not in gather else 20011
+    scale = torch.pow(10., torch.randint(-3, 3, (rows, K), generator=g).float())
+    x = (torch.randn(rows, K, generator=g) * scale).to(DEV)
+    a_idx = torch.randint(0, rows, (M,), generator=g, dtype=torch.int32).to(DEV) if 'a' in gather else None
+    c_idx = torch.randperm(M + 7, generator=g)[:M].to(torch.int32).to(DEV) if 'c' in gather else None
+    res = {}
+    if mode == 0:
+        w, b = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+        for flag in (True, False):
+            monkeypatch.setattr(ops, '_SPLIT', flag)
+            out = torch.full((M + 7 if c_idx is not None else M, N), 7.0, device=DEV)
+            _lib.CALL_LOG = []
+            ops.linear_nt(x, w, b, 1, a_idx=a_idx, out=out, c_idx=c_idx, n_rows=M)
+            names, _lib.CALL_LOG = [n for n, _ in _lib.CALL_LOG], None
+            assert ('sbr_gemm_split_wide_f32' in names) == flag, names
+            res[flag] = out
+        xa = x.double().cpu()[a_idx.cpu().long()] if a_idx is not None else x.double().cpu()
+        pre = xa @ w.double().cpu().t() + b.double().cpu()
+        ref = torch.relu(pre)
+        mag = xa.abs() @ w.double().cpu().abs().t() + b.double().cpu().abs()
+        if c_idx is not None:
+            untouched = torch.ones(M + 7, dtype=torch.bool)
+            untouched[c_idx.cpu().long()] = False
+            for flag in (True, False):
+                assert bool((res[flag].cpu()[untouched] == 7.0).all())          # rows no slot names are not written
+                res[flag] = res[flag][c_idx.long()]
+    else:
+        w = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+        for flag in (True, False):
+            monkeypatch.setattr(ops, '_SPLIT', flag)
+            _lib.CALL_LOG = []
+            res[flag] = ops.matmul_nn(x, w)
+            names, _lib.CALL_LOG = [n for n, _ in _lib.CALL_LOG], None
+            assert ('sbr_gemm_split_wide_f32' in names) == flag, names
+        ref = x.double().cpu() @ w.double().cpu()
+        mag = x.double().cpu().abs() @ w.double().cpu().abs()
+    e_split = ((res[True].double().cpu() - ref).abs() / mag).max().item()
+    e_f32 = ((res[False].double().cpu() - ref).abs() / mag).max().item()
+    assert e_split <= max(2.0 * e_f32, 2.0 ** -22), (e_split, e_f32)
+    rms_split = ((res[True].double().cpu() - ref) / mag).pow(2).mean().sqrt().item()
+    rms_f32 = ((res[False].double().cpu() - ref) / mag).pow(2).mean().sqrt().item()
+    assert rms_split <= max(2.0 * rms_f32, 2.0 ** -24), (rms_split, rms_f32)
 
 
 @pytest.mark.gpu

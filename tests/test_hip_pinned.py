@@ -394,7 +394,15 @@ def test_c3_step_at_full_shapes_against_the_cpu_oracle():
     loader = S().NegativeSamplingDataLoader(ds, batch_size=256, shuffle=True)
     u, i, labels = next(iter(loader))
     draws = fused.draw(u.shape, i.shape)
+    import importlib
+    _lib = importlib.import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    _lib.CALL_LOG = []
     total, rec, reg = fused.step(u, i, labels, draws)
+    names, _lib.CALL_LOG = [n_ for n_, _ in _lib.CALL_LOG], None
+    # 5,632 rows: the 256 -> 128 output layer on the bf16-split projector kernel, the weight gradients on the bf16-split dW kernel; the
+    # 512- and 256-wide forward / input-gradient products stay on the fp32 ring kernel at this batch (22 x 2 tiles of 256 x 256 do not
+    # fill the chip: ops._wide_ok) and move to the wide bf16-split kernel from ~22k rows on
+    assert 'sbr_gemm_split_proj_f32' in names and names.count('sbr_gemm_tn_f32_slabs') >= 6, names
     pos, order = draws[1]
     mods = np.array(order)[pos].reshape(tuple(i.shape) + (2,))
     ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
