@@ -128,35 +128,39 @@ __global__ __launch_bounds__(64 * SW_WAVES, 1) void gemm_split_wide_kernel(WideA
   };
 
   sp_f32x16 acc[8];
-  float4 r0[2][2], r1[2][2];                                     // two A chunks alternate: one is in flight while one is multiplied
-  auto mult_chunk = [&](int buf, const float4 (&raw)[2][2]) __attribute__((always_inline)) {
+  float4 r0[2][2];                                               // the wave's A chunk: refilled for the next step as soon as both k steps are split
+  // One step = 16 units (k step s, column tile j) of 6 MFMAs on one accumulator tile. The three weight fragments of unit u + 1 are
+  // requested BEFORE the MFMAs of unit u are issued and land in a second register set: left to itself hipcc issues every read one
+  // or two instructions ahead of the MFMA that needs it (no registers to hoist into at 256) and the wave sits out the LDS latency
+  // ~30 times per step (PMC: half of the wave cycles in s_waitcnt, matrix pipe 38 % busy). (Two tiles per unit — two independent
+  // accumulator chains — would need 48 fragment registers: spills.)
+  auto mult_chunk = [&](int buf, float4 (&raw)[2][2], const float* next_row, int next_kc) __attribute__((always_inline)) {
     const unsigned char* wfrag = smem + buf * SW_BUF + lane * 16;
+    sp_u32x4 w[2][3];                                            // [set][plane]
+    auto fetch = [&](int set, int s, int j) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      sp_u32x4 a0, a1, a2;
-      sp_split8(raw[s][0], raw[s][1], a0, a1, a2);
+      for (int p = 0; p < 3; ++p) w[set][p] = *(const sp_lds_u32x4*)(wfrag + p * SW_PL + ((j * 2 + s) * 64) * 16);
+    };
+    fetch(0, 0, 0);
+    sp_u32x4 a0, a1, a2;
+    sp_split8(raw[0][0], raw[0][1], a0, a1, a2);
 #pragma unroll
-      for (int jp = 0; jp < 4; ++jp) {                           // two column tiles at a time: two independent accumulator chains
-        sp_u32x4 w[2][3];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            w[jj][p] = *(const sp_lds_u32x4*)(wfrag + p * SW_PL + (((jp * 2 + jj) * 2 + s) * 64) * 16);
-        // smallest terms first
-        acc[jp * 2 + 0] = sp_mfma(a2, w[0][0], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a2, w[1][0], acc[jp * 2 + 1]);
-        acc[jp * 2 + 0] = sp_mfma(a0, w[0][2], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a0, w[1][2], acc[jp * 2 + 1]);
-        acc[jp * 2 + 0] = sp_mfma(a1, w[0][1], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a1, w[1][1], acc[jp * 2 + 1]);
-        acc[jp * 2 + 0] = sp_mfma(a1, w[0][0], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a1, w[1][0], acc[jp * 2 + 1]);
-        acc[jp * 2 + 0] = sp_mfma(a0, w[0][1], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a0, w[1][1], acc[jp * 2 + 1]);
-        acc[jp * 2 + 0] = sp_mfma(a0, w[0][0], acc[jp * 2 + 0]);
-        acc[jp * 2 + 1] = sp_mfma(a0, w[1][0], acc[jp * 2 + 1]);
+    for (int u = 0; u < 16; ++u) {
+      const int j = u & 7, set = u & 1;
+      if (u + 1 < 16) fetch(set ^ 1, (u + 1) >> 3, (u + 1) & 7);
+      __builtin_amdgcn_sched_barrier(0);                         // the reads of unit u + 1 stay in front of the MFMAs of unit u
+      // smallest terms first
+      acc[j] = sp_mfma(a2, w[set][0], acc[j]);
+      acc[j] = sp_mfma(a0, w[set][2], acc[j]);
+      acc[j] = sp_mfma(a1, w[set][1], acc[j]);
+      acc[j] = sp_mfma(a1, w[set][0], acc[j]);
+      acc[j] = sp_mfma(a0, w[set][1], acc[j]);
+      acc[j] = sp_mfma(a0, w[set][0], acc[j]);
+      if (u == 7) {
+        sp_split8(raw[1][0], raw[1][1], a0, a1, a2);             // the operands of k step 1 (behind the last MFMAs of k step 0)
+        if (next_row) load_chunk(next_row, next_kc, raw);        // both k steps are split: the A chunk of the next step takes the registers
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 1) void gemm_split_wide_kernel(WideA
   }
   __syncthreads();
 
-#define SW_STEP(CC, cur, fill) do { \
+#define SW_STEP(CC) do { \
     const int c = (CC); \
     if (c >= n_steps) break; \
     const int q = c / KC, kc = c - q * KC; \
@@ -187,12 +191,14 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f; \
     } \
+    const float* nrow = nullptr; \
+    int nkc = 0; \
     if (c + 1 < n_steps) {                                        /* A chunk of step c + 1 (of this tile or of the next one) */ \
       const int q1 = (c + 1) / KC, kc1 = (c + 1) - q1 * KC; \
       if (kc1 == 0) { int g1, c1; item_of(q1, g1, c1); ap = row_ptr(g1); } \
-      load_chunk(ap, kc1, fill); \
+      nrow = ap; nkc = kc1; \
     } \
-    mult_chunk(c & 1, cur); \
+    mult_chunk(c & 1, r0, nrow, nkc); \
     if (c + 1 < n_steps) { \
       store_w((c + 1) & 1); \
       if (c + 2 < n_steps) { \
@@ -228,8 +234,8 @@ _Pragma("unroll") \
   } while (0)
 #pragma unroll 1
   for (int c0 = 0; c0 < n_steps; c0 += 2) {
-    SW_STEP(c0, r0, r1);
-    SW_STEP(c0 + 1, r1, r0);
+    SW_STEP(c0);
+    SW_STEP(c0 + 1);
   }
 }
 
