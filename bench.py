@@ -92,8 +92,7 @@ def bench_training(S, ds, net, device, batch, steps, warmup, rank, world, time_k
     # three Python threads hand batches to each other (collate -> prepare -> launch). With CPython's default 5 ms switch
     # interval a waiting thread can sit behind the GIL for longer than a whole small-batch step; measured best: 0.2 ms at
     # B = 256 (0.36 vs 0.59 ms per step), 1 ms at B = 8192.
-    if 'SBR_SWITCH_INTERVAL' not in os.environ:
-        sys.setswitchinterval(2e-4 if batch <= 1024 else 1e-3)
+    sys.setswitchinterval(2e-4 if batch <= 1024 else 1e-3)
     # weak scaling: every rank collates its own per-GPU batch (dp_sampling='local': contiguous slice of the shared epoch order,
     # rank-seeded negative stream) — the bit-exact 'global' mode makes every rank draw the whole global batch on its host
     np.random.seed(42 + rank)
@@ -772,8 +771,6 @@ def main():
         sys.exit(launch_ranks(args.gpus))
 
     import torch.distributed as dist
-    if 'SBR_SWITCH_INTERVAL' in os.environ:
-        sys.setswitchinterval(float(os.environ['SBR_SWITCH_INTERVAL']))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     # torch CPU ops of the loader threads: stay inside the job's CPU quota, shared by the ranks of the node
     torch.set_num_threads(max(1, host_cores() // int(os.environ.get('LOCAL_WORLD_SIZE', world))))

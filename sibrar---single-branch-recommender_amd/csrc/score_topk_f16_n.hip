@@ -930,10 +930,6 @@ static int s5_pick_waves(long Bu) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  if (getenv("SBR_ST_WAVES")) {
-    int w = atoi(getenv("SBR_ST_WAVES"));
-    return w < 1 ? 1 : (w > S5_MAXW ? S5_MAXW : w);
-  }
   const long units = sbr_cdiv(Bu, 32);
   const long rounds = sbr_cdiv(units, (long)n_cu * S5_MAXW);
   long w = sbr_cdiv(units, rounds * n_cu);

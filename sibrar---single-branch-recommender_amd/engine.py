@@ -566,7 +566,7 @@ class FusedTrainStep:
         self.arena = Arena(dev)
         self.user = (_EntityRun if net.is_user_sb_module else _PlainRun)(net.user_embedding_module, self.arena)
         self.item = _EntityRun(net.item_embedding_module, self.arena)
-        self.item.fuse_tail = os.environ.get('SBR_FUSE_TAIL', '1') != '0'
+        self.item.fuse_tail = True   # the trailing BatchNorm runs inside the scorer whenever a step draws one modality per slot
         self.kind = {RecBinaryCrossEntropy: 0, RecBayesianPersonalizedRankingLoss: 1, RecSampledSoftmaxLoss: 2}[type(rec_loss)]
         self.one64 = torch.ones((), device=dev, dtype=torch.float64)
         self.one32 = torch.ones((), device=dev, dtype=torch.float32)
