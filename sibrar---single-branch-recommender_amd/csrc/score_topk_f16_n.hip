@@ -74,88 +74,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define S5_RF 32                         // tiles between two threshold refreshes in the steady state
 #endif
 
-// All 64 lanes: the k best of the n0 + n1 raw entries of a user's two buffer halves (each <= S5_CAPH: lane l holds entries l, l + 64,
-// ... of both) are found by a bitwise binary search for the k-th largest score key over ballot counts (ties at that key: smallest
-// item indices stay). COMPACT: the survivors are stored back raw, unsorted — k - k / 2 to b0[0 ..) and k / 2 to b1[0 ..) (overflow
-// path of the scorer: both halves keep room) — else all of them to b0[0 .. k) (finalize kernel). Fewer than k entries: with COMPACT
-// nothing moves and -inf is returned; without, all n0 + n1 entries are gathered into b0[0 .. n0 + n1). Returns the k-th best score.
-template <bool SPLIT>
-__device__ __forceinline__ float s5_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane) {
-  const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
-  // written and read by this wave only: same-CU vector memory path, in order
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  unsigned long long raw[2 * S5_EH], e[2 * S5_EH];
-#pragma unroll
-  for (int j = 0; j < S5_EH; ++j) {
-    raw[j] = lane + 64 * j < n0 ? b0[lane + 64 * j] : 0ull;
-    raw[S5_EH + j] = lane + 64 * j < n1 ? b1[lane + 64 * j] : 0ull;
-  }
-#pragma unroll
-  for (int j = 0; j < 2 * S5_EH; ++j) {
-    const bool have = lane + 64 * (j % S5_EH) < (j < S5_EH ? n0 : n1);
-    e[j] = have ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw[j] >> 32))) << 32) | (raw[j] & 0xFFFFFFFFull)) : 0ull;
-  }
-  const int c0 = (n0 + 63) >> 6, c1 = (n1 + 63) >> 6;        // occupied 64-entry chunks per half (wave-uniform)
-  auto count_ge = [&](unsigned long long C) {
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < S5_EH; ++j) {
-      if (j < c0) cnt += __popcll(__ballot(e[j] >= C));
-      if (j < c1) cnt += __popcll(__ballot(e[S5_EH + j] >= C));
-    }
-    return cnt;
-  };
-  if (n0 + n1 < k) {
-    if constexpr (SPLIT) return -INFINITY;
-    // gather: half 1's entries behind half 0's (n0 + n1 < k <= 32 <= 64: one chunk each)
-    if (lane < n1) b0[n0 + lane] = raw[S5_EH];
-    return -INFINITY;
-  }
-  // k-th largest composite key (score key << 32 | ~item): composites are unique, so exactly k entries lie at or above it. The
-  // search runs on the high word first (32 steps at most; it stops as soon as EXACTLY k entries lie at or above the prefix found
-  // so far) and on the low word only when several entries share the k-th score key.
-  unsigned int T = 0u;
-  int c_ge = n0 + n1;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned int trial = T | (1u << bit);
-    const int cnt = count_ge((unsigned long long)trial << 32);
-    if (cnt >= k) { T = trial; c_ge = cnt; if (cnt == k) break; }
-  }
-  unsigned long long C = (unsigned long long)T << 32;
-  if (c_ge != k) {                                           // several entries share the k-th key: smallest item indices stay
-    unsigned int Lw = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned int trial = Lw | (1u << bit);
-      // entries with a larger score key count as well: (T + 1) << 32 > any (T, low) composite
-      const int cnt = count_ge(((unsigned long long)T << 32) | trial);
-      Lw = cnt >= k ? trial : Lw;
-    }
-    C |= (unsigned long long)Lw;
-  }
-  // survivors to their places, in (chunk, lane) order
-  const int kh = SPLIT ? k - (k >> 1) : k;                   // survivors 0 .. kh - 1 go to b0, the rest to b1
-  int before = 0;
-#pragma unroll
-  for (int j = 0; j < 2 * S5_EH; ++j) {
-    const bool live = (j < S5_EH) ? (j < c0) : (j - S5_EH < c1);
-    if (live) {
-      const bool keep = e[j] >= C;
-      const unsigned long long m = __ballot(keep);
-      const int p = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-      if (keep) (p < kh ? b0 + p : b1 + (p - kh))[0] = raw[j];
-      before += __popcll(m);
-    }
-  }
-  // T may be a PREFIX of the k-th key (low bits clear): as a float that is a value at or below the k-th best score — a valid
-  // threshold — except that clearing into the exponent of a negative score can produce a NaN pattern: no bound then
-  const float t = st_key2f(T);
-  return t == t ? t : -INFINITY;
-}
-
-// The same selection for the scorer's OVERFLOW path (a (user, half) buffer ran full: ties at the threshold, or a threshold that
-// cannot rise), written for few registers instead of speed — the entries are re-read from the buffers in every round of the search
-// instead of being held in 2 x S5_EH register pairs per lane, which would cost the hot loop its fourth wave per SIMD. Survivors go
-// back split over both halves (k - k / 2 and k / 2: both keep room). Returns the k-th best score; -inf (nothing moved) below k entries.
+// All 64 lanes: the scorer's OVERFLOW path (a (user, half) buffer ran full: ties at the threshold, or a threshold that cannot rise).
+// The k best of the n0 + n1 raw entries of a user's two buffer halves are found by a bitwise binary search for the k-th largest
+// composite key (score key << 32 | ~item: ties at the k-th score keep the smallest item indices) over ballot counts; written for few
+// registers instead of speed — the entries are re-read from the buffers in every round of the search instead of being held in
+// 2 x S5_EH register pairs per lane, which would cost the hot loop its fourth wave per SIMD. Survivors go back split over both
+// halves (k - k / 2 and k / 2: both keep room). Returns the k-th best score; -inf (nothing moved) below k entries.
 __device__ __forceinline__ float s5_overflow_select(unsigned long long* b0, unsigned long long* b1, int n0_any, int n1_any, int k, int lane) {
   const int n0 = __builtin_amdgcn_readfirstlane(n0_any), n1 = __builtin_amdgcn_readfirstlane(n1_any);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // written and read by this wave only
@@ -372,7 +296,7 @@ __device__ __forceinline__ void s5_pin8(const f16x8& a) { asm volatile("" ::"v"(
 template <int KS, int NS, int NJ, int DBG, bool PRE>   // KS = D / 16; NS = LDS ring slots; NJ = 32-item accumulator tiles per LDS tile; DBG: ablations; PRE: prefix pass compiled in
 __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, const unsigned int* __restrict__ events,
-    const int* __restrict__ group_base, int item_offset, int k, int n_pre, int W,
+    const int* __restrict__ group_base, int item_offset, int k, int n_pre, int W, int n_part, int P,
     int* __restrict__ cnt_out, unsigned long long* __restrict__ gbuf, unsigned long long* __restrict__ dbgbuf) {
   constexpr int D = KS * 16;
   constexpr int ST_TILE = 32 * NJ;
@@ -398,24 +322,39 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const long row0 = (long)blockIdx.x * (W * 32);
+  // Work units = 32 users x the whole catalogue. A workgroup has W FULL consumer waves (unit blockIdx.x * W + wave); when the units
+  // do not divide evenly over the CUs, the remainder units are each cut into P PARTS by item tile (tile t belongs to part t % P) and
+  // workgroup b < n_part gets one more consumer wave for part b % P of remainder unit b / P — with its own candidate buffers, merged by
+  // the final selection. (One unit more per workgroup instead would put a fourth consumer wave on ONE SIMD of every CU: that SIMD's
+  // instruction stream sets the pace of the whole workgroup through the tile ring — cycle stamps: the other waves waited a quarter
+  // of their time.)
+  const int Wb = W + ((int)blockIdx.x < n_part ? 1 : 0);  // consumer waves of THIS workgroup
+  const bool partial = wave == W && (int)blockIdx.x < n_part;                       // wave-uniform
+  const int part = partial ? (int)blockIdx.x % P : 0, n_parts = partial ? P : 1;
+  const long n_full_units = (long)gridDim.x * W;
+  const long unit = partial ? n_full_units + (int)blockIdx.x / P : (long)blockIdx.x * W + wave;      // 32-user group of this wave
+  // rows of the candidate buffers / fill counts: a full wave uses its users' rows, a partial wave rows behind all units
+  const long n_units = (Bu + 31) >> 5;
+  const long brow0 = partial ? n_units * 32 + (long)blockIdx.x * 32 : unit * 32;
   const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
   const int n_virt = n_pre + n_tiles;                      // tile sequence: prefix tiles 0 .. n_pre - 1, then all tiles
 
   if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
   __syncthreads();                                         // the only workgroup barrier of the kernel
 
-  if (wave >= W) {
+  const int cslots = W + (n_part > 0 ? 1 : 0);             // wave slots in front of the loader waves
+  if (wave == W && n_part > 0 && !partial) return;         // the slot of the partial wave in a workgroup that has none
+  if (wave >= cslots) {
     if constexpr (DBG == 5) return;                        // lab: consumers run over whatever the ring holds, no loads, no hand-off
     // ---------------------------------------------- loader waves -----------------------------------------------------
     // S5_NL waves take the tiles in turn (tile v belongs to loader v % S5_NL): one wave's LDS-DMA stream tops out near one
     // 16 KB tile per 0.65 us, which is what fourteen consumer waves eat
-    const int lw = wave - W;
+    const int lw = wave - cslots;
     int n_mine = 0, v_last = -1;
     for (int v = lw; v < n_virt; v += S5_NL) {
       const int slot = v % NS;
       if (v >= NS) {
-        const int need = W * (v / NS);
+        const int need = Wb * (v / NS);
         while (st_peek(free_lds + slot) < need) __builtin_amdgcn_s_sleep(1);
       }
       const int j0 = (v < n_pre ? v : v - n_pre) * ST_TILE;
@@ -452,7 +391,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   // B-operand fragments of the wave's 32-user tile: user 32 * wave + l31, k = 16 s + 8 half + j
   f16x8 ufrag[KS];
   {
-    const long r = row0 + wave * 32 + l31;
+    const long r = unit * 32 + l31;
     const long ur = r < Bu ? r : Bu - 1;
     const f16x8* src = reinterpret_cast<const f16x8*>(U + ur * D);
 #pragma unroll
@@ -463,7 +402,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s) s5_pin8(ufrag[s]);
   }
-  unsigned long long* wgb = gbuf + (row0 + (long)wave * 32) * (2 * S5_CAPH);      // wave-uniform: buffers of the wave's 32 users
+  unsigned long long* wgb = gbuf + brow0 * (2 * S5_CAPH);      // wave-uniform: buffers of the wave's 32 users
   const i32x4 wrs = s5_block_rsrc(wgb);
   // Exclusions arrive as a wave-uniform EVENT stream (s5_build_events): for this wave's 32 users, one 32-bit word per excluded
   // (user, item) of the scored item range, ordered by item tile: tile << 11 | lane that holds the accumulator << 5 | its bit.
@@ -472,7 +411,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   // stores (a per-lane walk of the CSR rows has to wait on vmcnt, i.e. for every store in flight), and a user with thousands of
   // exclusions costs its events, not a serialised round per entry for the whole wave.
   // (a wave past the last user group — padding of the last workgroup — has no group_base entry: it runs without events)
-  const bool has_excl = events != nullptr && (row0 >> 5) + wave < ((Bu + 31) >> 5);      // wave-uniform
+  const bool has_excl = events != nullptr && unit < n_units;      // wave-uniform
   // (read through the CONSTANT address space: hipcc turns a wave-uniform load from global memory into s_load only when it can
   // prove that nothing in the kernel writes there; it could not, used global_load_dwordx4 + VGPRs for the window, and the wait for
   // that load — vmcnt(0), i.e. for every candidate store in flight — sat inside the event loop: +0.28 ms per pass)
@@ -488,7 +427,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     w0 = qa.x; w1 = qa.y; w2 = qa.z; w3 = qa.w; n0 = qb.x; n1 = qb.y; n2 = qb.z; n3 = qb.w;                             \
     ev_rem = 4; ev_q = 8;                                                                                                \
   }
-  if (has_excl) evp = (ev_ptr)events + ((const __attribute__((address_space(4))) int*)group_base)[(row0 >> 5) + wave];
+  if (has_excl) evp = (ev_ptr)events + ((const __attribute__((address_space(4))) int*)group_base)[unit];
   S5_EV_RESTART()
   int peek = 0;
   int slot_next = 0;                                       // ring slot of the next tile of the sequence
@@ -503,6 +442,31 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   const unsigned long long rt_begin = DBG != 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+  // the event window moves on by one event (a quad at a time is refilled by a scalar load, one quad ahead)
+#define S5_EV_NEXT()                                                                                                     \
+        w0 = w1; w1 = w2; w2 = w3;                                                                                       \
+        if (--ev_rem == 0) {                                                                                             \
+          w0 = n0; w1 = n1; w2 = n2; w3 = n3;                                                                            \
+          if constexpr (S5_EVABL == 1) { n0 = n1 = n2 = n3 = S5_EV_NONE; } else {                                       \
+          const ev_quad qn = *(ev_quad_ptr)(evp + ev_q);                                                                 \
+          n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w; }                                                                  \
+          ev_rem = 4; ev_q += 4;                                                                                         \
+        }
+  // a tile that is not this (partial) wave's: wait for it, release it, pass its exclusion events by — the wave stays in step with
+  // the ring (a slot may only be released after its tile has been published: the loader counts releases per slot)
+#define S5_TILE_SKIP(V, J0)                                                                                              \
+  {                                                                                                                      \
+    const int slot = slot_next;                                                                                          \
+    slot_next = slot + 1 == NS ? 0 : slot + 1;                                                                           \
+    if (DBG != 5) { while (st_peek(full_lds + slot) != (V) + 1) __builtin_amdgcn_s_sleep(1); }                           \
+    st_wave_fence();                                                                                                     \
+    if constexpr (DBG != 5) s5_lds_add_lane0(free_lds + slot, 1);                                                        \
+    peek = 0;                                                                                                            \
+    if (has_excl) {                                                                                                      \
+      const unsigned int tkey = (unsigned int)((J0) / ST_TILE);                                                          \
+      while ((w0 >> 11) == tkey) { S5_EV_NEXT() }                                                                        \
+    }                                                                                                                    \
+  }
   // one item tile: wait, MFMAs (S^T = I x U^T), slot release, exclusion bits of the tile -> acc, have_ex
 #define S5_TILE_BODY(V, PFV)                                                                                                 \
     const int slot = slot_next;                            /* = (V) % NS, kept as a wrapping counter */                    \
@@ -553,14 +517,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       while ((w0 >> 11) == tkey) {                                                                                       \
         ex |= lane == (int)((w0 >> 5) & 63u) ? 1u << (w0 & 31u) : 0u;                                                    \
         have_ex = true;                                                                                                  \
-        w0 = w1; w1 = w2; w2 = w3;                                                                                       \
-        if (--ev_rem == 0) {                                                                                             \
-          w0 = n0; w1 = n1; w2 = n2; w3 = n3;                                                                            \
-          if constexpr (S5_EVABL == 1) { n0 = n1 = n2 = n3 = S5_EV_NONE; } else {                                       \
-          const ev_quad qn = *(ev_quad_ptr)(evp + ev_q);                                                                 \
-          n0 = qn.x; n1 = qn.y; n2 = qn.z; n3 = qn.w; }                                                                  \
-          ev_rem = 4; ev_q += 4;                                                                                         \
-        }                                                                                                                \
+        S5_EV_NEXT()                                                                                                     \
       }                                                                                                                  \
     }
 
@@ -569,7 +526,10 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   float cm[16];                                            // item class = (lane half, accumulator register): 32 per user
 #pragma unroll
   for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
-  if (PRE && n_pre > 0) {
+  if (partial) {
+    for (int v = 0; v < n_pre; ++v) S5_TILE_SKIP(v, v * ST_TILE)
+    S5_EV_RESTART()
+  } else if (PRE && n_pre > 0) {
     for (int v = 0; v < n_pre; ++v) {
       const int j0 = v * ST_TILE;
       S5_TILE_BODY(v, PF_PRE)
@@ -619,8 +579,14 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   const int pos_limit = lane_base + LIMIT * 8;
   // threshold refresh from the class maxima: after tiles 0, 1, 2, 3, 5, 8, 12, ... (gaps growing by half) while the thresholds are
   // still crude, every S5_RF tiles in the steady state
-  int next_rf = n_pre > 0 ? S5_RF - 1 : 0;
+  int next_rf = (n_pre > 0 && !partial) ? S5_RF - 1 : 0;
+  int part_next = part;                                    // next tile of this part (a full wave: every tile)
   for (int tl = 0; tl < n_tiles; ++tl) {
+    if (tl != part_next) {                                 // (partial waves only) another part's tile
+      S5_TILE_SKIP(n_pre + tl, tl * ST_TILE)
+      continue;
+    }
+    part_next += n_parts;
     if (__ballot(pos > pos_limit)) {
       // ---- overflow (cold): a (user, half) buffer is nearly full — select that user's k best so that this tile's appends fit
       const unsigned long long tm0 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -705,7 +671,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     }
     if constexpr (DBG == 4) t_ladder += __builtin_amdgcn_s_memtime() - ti1;
     if constexpr (DBG == 3) t_ladder += __builtin_amdgcn_s_memtime() - t_mid;
-    if (tl == next_rf) {
+    if (tl >= next_rf) {
       // every later item has a larger index than the k buffered items at or above the bound: it needs a strictly larger score
       if constexpr (CML) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ds_max updates have been performed
@@ -720,6 +686,8 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     }
   }
 #undef S5_TILE_BODY
+#undef S5_TILE_SKIP
+#undef S5_EV_NEXT
 
   if constexpr (DBG != 0) {
     if (lane == 0 && dbgbuf) {
@@ -733,58 +701,138 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     int2 o;
     o.x = (pos - lane_base) >> 3;
     o.y = (int)__float_as_uint(thr);
-    reinterpret_cast<int2*>(cnt_out)[(row0 + (long)wave * 32 + l31) * 2 + half] = o;
+    reinterpret_cast<int2*>(cnt_out)[(brow0 + l31) * 2 + half] = o;
   }
 }
 
-// ---- final selection: one wave per user, four users per workgroup. Only buffered candidates at or above the user's final
-// threshold can be among its k best (k buffered items lie at or above it): they are filtered first (~25 of ~110), gathered into one
-// entry per lane through LDS, ranked by counting (score desc, item index asc) and the lanes of rank < k write the output. More than
-// 64 survivors (ties at the threshold) or a threshold that never rose: the general selection (s5_select: bitwise binary search over
-// ballot counts) picks the k best first. Empty slots (-inf, -1) behind fewer than k candidates.
-__global__ __launch_bounds__(256) void score_topk_finalize_kernel(long Bu, int k, const int* __restrict__ cnt, unsigned long long* __restrict__ gbuf,
-                                                                  float* __restrict__ out_val, int* __restrict__ out_idx) {
-  __shared__ unsigned long long stage[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// ---- final selection: one wave per user, four users per workgroup. A user's candidates sit in ONE pair of buffer halves (its unit
+// was scored by a full wave) or in P pairs (a remainder unit cut into P parts by item tile, see the scorer). Only candidates at or
+// above the largest of the sources' final thresholds can be among the k best (k buffered items lie at or above each): they are
+// filtered first (~25 of ~110), gathered into one entry per lane through LDS, ranked by counting (score desc, item index asc) and the
+// lanes of rank < k write the output. More than 64 survivors (ties at the threshold, a threshold that never rose): a bitwise binary
+// search over ballot counts (entries re-read per round: cold) finds the k-th largest composite key first and exactly k survive.
+// Empty slots (-inf, -1) behind fewer than k candidates.
+__global__ __launch_bounds__(256) void score_topk_finalize_kernel(long Bu, int k, long n_full_units, int P, const int* __restrict__ cnt,
+                                                                  const unsigned long long* __restrict__ gbuf, float* __restrict__ out_val,
+                                                                  int* __restrict__ out_idx) {
+  constexpr int CAP = 256;                                   // survivors a wave can stage in LDS
+  __shared__ unsigned long long stage[4][CAP];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long ur = (long)blockIdx.x * 4 + w;
   if (ur >= Bu) return;                                      // wave-uniform
-  const int4 c = reinterpret_cast<const int4*>(cnt)[ur];     // (n0, thr bits, n1, thr bits) of the user's two halves
-  const int n0 = __builtin_amdgcn_readfirstlane(c.x), n1 = __builtin_amdgcn_readfirstlane(c.z);
-  const float thr = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane(c.y));
-  unsigned long long* b0 = gbuf + ur * (2 * S5_CAPH);
-  unsigned long long* b1 = b0 + S5_CAPH;
-  // ---- filter + gather
-  const int c0 = (n0 + 63) >> 6, c1 = (n1 + 63) >> 6;
-  int total = 0;
-  bool fits = true;
+  const long unit = ur >> 5, n_units = (Bu + 31) >> 5;
+  const int n_src = unit < n_full_units ? 1 : P;
+  const long row_first = unit < n_full_units ? ur : n_units * 32 + (unit - n_full_units) * P * 32 + (ur & 31);      // + 32 per part
+  auto key_of = [&](unsigned long long raw) -> unsigned long long {     // 0 for an empty slot (raw entries are never 0: ~item != 0)
+    return raw ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw >> 32))) << 32) | (raw & 0xFFFFFFFFull)) : 0ull;
+  };
+  const int4 c_first = reinterpret_cast<const int4*>(cnt)[row_first];
+  float thr = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane(c_first.y));
+  // every (source, half, 64-entry chunk) in a fixed order; f(raw entry of this lane or 0). The loads of a source are issued together.
+  auto for_chunks = [&](auto&& f) {
+    for (int sidx = 0; sidx < n_src; ++sidx) {
+      const long row = row_first + 32L * sidx;
+      const int4 c = sidx == 0 ? c_first : reinterpret_cast<const int4*>(cnt)[row];       // (n0, thr bits, n1, thr bits)
+      const int n0 = __builtin_amdgcn_readfirstlane(c.x), n1 = __builtin_amdgcn_readfirstlane(c.z);
+      const unsigned long long* b0 = gbuf + row * (2 * S5_CAPH);
+      unsigned long long raw[2 * S5_EH];
 #pragma unroll
-  for (int j = 0; j < 2 * S5_EH; ++j) {
-    const bool first = j < S5_EH;
-    const int jj = first ? j : j - S5_EH;
-    if (jj < (first ? c0 : c1)) {                            // wave-uniform
-      const int q = lane + 64 * jj;
-      const unsigned long long raw = q < (first ? n0 : n1) ? (first ? b0 : b1)[q] : 0ull;
-      const bool keep = q < (first ? n0 : n1) && __uint_as_float((unsigned int)(raw >> 32)) >= thr;
-      const unsigned long long m = __ballot(keep);
-      const int p = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-      if (keep && p < 64) stage[w][p] = raw;
-      total += __popcll(m);
-      fits = fits && total <= 64;
+      for (int j = 0; j < 2 * S5_EH; ++j) {
+        const int hh = j / S5_EH, q = (j % S5_EH) * 64 + lane;
+        raw[j] = q < (hh ? n1 : n0) ? b0[hh * S5_CAPH + q] : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * S5_EH; ++j) {
+        if ((j % S5_EH) * 64 < (j / S5_EH ? n1 : n0)) f(raw[j]);                  // wave-uniform
+      }
     }
+  };
+  for (int sidx = 1; sidx < n_src; ++sidx) {
+    const float t = __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane(cnt[(row_first + 32L * sidx) * 4 + 1]));
+    thr = t > thr ? t : thr;
   }
-  unsigned long long raw = 0ull;
-  int n;
-  if (fits) {
-    n = total;
-    st_wave_fence();                                         // LDS operations of a wave execute in order
-    raw = lane < n ? stage[w][lane] : 0ull;
+  // ---- gather the candidates at or above the threshold, one per lane
+  unsigned long long cut = 0ull;                             // survivors: composite key >= cut (when the filter lets too many through)
+  int n = 0;
+  auto gather = [&](unsigned long long raw) {
+    const bool keep = raw != 0ull && (cut ? key_of(raw) >= cut : __uint_as_float((unsigned int)(raw >> 32)) >= thr);
+    const unsigned long long m = __ballot(keep);
+    const int p = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (keep && p < CAP) stage[w][p] = raw;
+    n += __popcll(m);
+  };
+  for_chunks(gather);
+  if (n > CAP) {                                             // cold: exactly k survive a cut at the k-th largest composite key
+    auto count_ge = [&](unsigned long long C) {
+      int cn = 0;
+      for_chunks([&](unsigned long long raw) { cn += __popcll(__ballot(key_of(raw) >= C && raw != 0ull)); });
+      return cn;
+    };
+    unsigned int T = 0u;
+    int c_ge = 1 << 30;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = T | (1u << bit);
+      const int cn = count_ge((unsigned long long)trial << 32);
+      if (cn >= k) { T = trial; c_ge = cn; if (cn == k) break; }
+    }
+    cut = (unsigned long long)T << 32;
+    if (c_ge != k) {
+      unsigned int Lw = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = Lw | (1u << bit);
+        Lw = count_ge(((unsigned long long)T << 32) | trial) >= k ? trial : Lw;
+      }
+      cut |= (unsigned long long)Lw;
+    }
+    st_wave_fence();
+    n = 0;
+    for_chunks(gather);
+  }
+  st_wave_fence();                                           // LDS operations of a wave execute in order
+  unsigned long long e;
+  if (n <= 64) {
+    e = key_of(lane < n ? stage[w][lane] : 0ull);
   } else {
-    s5_select<false>(b0, b1, n0, n1, k, lane);
-    n = n0 + n1 < k ? n0 + n1 : k;                           // survivors, in b0[0 .. n)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    raw = lane < n ? b0[lane] : 0ull;
+    // 65 .. CAP survivors (a user of a remainder unit: the parts' thresholds are those of a quarter of the catalogue each): the same
+    // search for the k-th largest composite key, over registers
+    unsigned long long e4[CAP / 64];
+#pragma unroll
+    for (int q = 0; q < CAP / 64; ++q) e4[q] = key_of(q * 64 + lane < n ? stage[w][q * 64 + lane] : 0ull);
+    auto count_ge = [&](unsigned long long C) {
+      int cn = 0;
+#pragma unroll
+      for (int q = 0; q < CAP / 64; ++q) cn += __popcll(__ballot(e4[q] >= C));
+      return cn;
+    };
+    unsigned int T = 0u;
+    int c_ge = 1 << 30;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = T | (1u << bit);
+      const int cn = count_ge((unsigned long long)trial << 32);
+      if (cn >= k) { T = trial; c_ge = cn; if (cn == k) break; }
+    }
+    unsigned long long kcut = (unsigned long long)T << 32;
+    if (c_ge != k) {
+      unsigned int Lw = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = Lw | (1u << bit);
+        Lw = count_ge(((unsigned long long)T << 32) | trial) >= k ? trial : Lw;
+      }
+      kcut |= (unsigned long long)Lw;
+    }
+    st_wave_fence();
+    n = 0;
+#pragma unroll
+    for (int q = 0; q < CAP / 64; ++q) {
+      const bool keep = e4[q] >= kcut && e4[q] != 0ull;
+      const unsigned long long m = __ballot(keep);
+      const int p = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+      if (keep && p < 64) stage[w][p] = e4[q];
+      n += __popcll(m);
+    }
+    st_wave_fence();
+    e = lane < n ? stage[w][lane] : 0ull;
   }
-  const unsigned long long e = lane < n ? (((unsigned long long)st_f2key(__uint_as_float((unsigned int)(raw >> 32))) << 32) | (raw & 0xFFFFFFFFull)) : 0ull;
   const int h32 = (int)(e >> 32), l32 = (int)e;
   int rk = 0;
   for (int j = 0; j < n; ++j) {
@@ -920,9 +968,7 @@ __global__ __launch_bounds__(256) void s5_ev_scatter_kernel(long Bu, const int* 
   for (int i = cnt + t; i < alloc; i += 256) events[base + i] = S5_EV_NONE;
 }
 
-// consumer waves per workgroup: users are dealt in 32-user units over the CUs; the smallest W that keeps the number of rounds
-// (workgroups per CU, one resident at a time) at its minimum
-static int s5_pick_waves(long Bu) {
+static int s5_n_cu() {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -930,10 +976,30 @@ static int s5_pick_waves(long Bu) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
+  return n_cu;
+}
+
+// How the 32-user units are dealt to workgroups (one resident per CU): W full consumer waves per workgroup on n_wg workgroups, plus —
+// when the units do not divide evenly over the CUs — one PARTIAL wave on each of the first n_part workgroups: the remainder units are
+// cut into P parts by item tile (see the kernel). 100k users = 3,125 units on 256 CUs: 12 full waves everywhere + 53 remainder units
+// in 4 parts each on 212 workgroups (3.25 consumer waves on the fullest SIMD instead of 4).
+struct S5Plan { int W, n_wg, n_part, P; };
+static S5Plan s5_plan(long Bu) {
+  const int G = s5_n_cu();
   const long units = sbr_cdiv(Bu, 32);
-  const long rounds = sbr_cdiv(units, (long)n_cu * S5_MAXW);
-  long w = sbr_cdiv(units, rounds * n_cu);
-  return (int)(w < 1 ? 1 : (w > S5_MAXW ? S5_MAXW : w));
+  S5Plan p;
+  const long Wf = units / G;
+  const long R = units - Wf * G;
+  if (Wf >= 1 && Wf + 1 <= S5_MAXW && R > 0 && G / R >= 2) {
+    p.W = (int)Wf; p.n_wg = G; p.P = (int)(G / R < 8 ? G / R : 8); p.n_part = (int)(R * p.P);
+    return p;
+  }
+  // one round of whole units: the smallest W that keeps the number of rounds (workgroups per CU) at its minimum
+  const long rounds = sbr_cdiv(units, (long)G * S5_MAXW);
+  long w = sbr_cdiv(units, rounds * G);
+  p.W = (int)(w < 1 ? 1 : (w > S5_MAXW ? S5_MAXW : w));
+  p.n_wg = (int)sbr_cdiv(units, p.W); p.n_part = 0; p.P = 1;
+  return p;
 }
 
 // Exclusion events of one (user list, exclusion CSR, item range, tile width) combination: group_base int[G + 1], grp_cnt int[G],
@@ -949,11 +1015,11 @@ static long s5_event_bytes(long Bu, long excl_nnz) {
 }
 extern "C" long sbr_score_topk_f16_events_bytes(long Bu, long excl_nnz) { return s5_event_bytes(Bu, excl_nnz); }
 
-static long s5_padded_users(long Bu) { return Bu + 32L * S5_MAXW; }      // users padded to whole workgroups of any wave count
+static long s5_padded_users(long Bu) { return sbr_cdiv(Bu, 32) * 32 + 32L * S5_MAXW + 32L * s5_n_cu(); }      // whole units + the last workgroup's padding + one row group per partial wave
 static long s5_workspace_bytes(long Bu) {
   // candidate buffers + fill counts + the cycle stamps of SBR_ST_DEBUG
   const long padded = s5_padded_users(Bu);
-  return padded * 2 * S5_CAPH * 8 + s5_al16(padded * 2 * 8) + s5_al16((sbr_cdiv(Bu, 32) + S5_MAXW) * S5_MAXW * 64L);
+  return padded * 2 * S5_CAPH * 8 + s5_al16(padded * 2 * 8) + s5_al16((sbr_cdiv(Bu, 32) + S5_MAXW + s5_n_cu()) * S5_MAXW * 64L);
 }
 
 struct S5Events { const unsigned int* events; const int* group_base; };
@@ -997,12 +1063,13 @@ template <int KS, int NS, int NJ, bool PRE>
 static int s5_launch(const void* U, const void* It, long Bu, int I, const long* u_idx, const long* eptr, const int* eidx, long excl_nnz,
                      int item_offset, int k, float* out_val, int* out_idx, void* workspace, long workspace_bytes, void* ev_buf,
                      long ev_bytes, int build_events, hipStream_t s) {
-  const int W = s5_pick_waves(Bu);
-  const long n_wg = sbr_cdiv(Bu, 32L * W);
+  const S5Plan plan = s5_plan(Bu);
+  const int W = plan.W;
+  const long n_wg = plan.n_wg;
   const long padded = s5_padded_users(Bu);
   const long buf_bytes = padded * 2 * S5_CAPH * 8, cnt_bytes = s5_al16(padded * 2 * 8);
   const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2 | 5 | 6 | 7: timing-only ablations, 4: cycle stamps
-  SBR_REQUIRE(n_wg * 32L * W <= padded, "sbr_score_topk_f16: internal: padding");
+  SBR_REQUIRE(n_wg * 32L * W + 32L * plan.n_part <= padded && sbr_cdiv(Bu, 32) * 32 + 32L * plan.n_part <= padded, "sbr_score_topk_f16: internal: padding");
   SBR_REQUIRE(workspace && workspace_bytes >= s5_workspace_bytes(Bu),
               "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", s5_workspace_bytes(Bu), workspace_bytes);
   int* cnt = (int*)((char*)workspace + buf_bytes);
@@ -1031,10 +1098,12 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;
   }
-  kern<<<(unsigned int)n_wg, (W + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, evs.events, evs.group_base, item_offset, k,
-                                                   n_pre, W, cnt, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
+  // (a full wave of the last workgroups may own a unit past the last user: it scores a copy of the last user and nobody reads its buffers)
+  kern<<<(unsigned int)n_wg, (W + (plan.n_part > 0 ? 1 : 0) + S5_NL) * 64, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, evs.events, evs.group_base, item_offset, k,
+                                                       n_pre, W, plan.n_part, plan.P, cnt, (unsigned long long*)workspace, (unsigned long long*)dbg_buf);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16");
-  score_topk_finalize_kernel<<<(unsigned int)sbr_cdiv(Bu, 4), 256, 0, s>>>(Bu, k, cnt, (unsigned long long*)workspace, out_val, out_idx);
+  score_topk_finalize_kernel<<<(unsigned int)sbr_cdiv(Bu, 4), 256, 0, s>>>(Bu, k, plan.n_part > 0 ? (long)n_wg * W : (1L << 40), plan.P, cnt,
+                                                                            (const unsigned long long*)workspace, out_val, out_idx);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16 (final selection)");
   return SBR_OK;
 }
