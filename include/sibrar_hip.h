@@ -366,15 +366,6 @@ int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, float* v, lo
 int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64, const int* ids32,
                   const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1, double b2, double eps,
                   double wd, long step, void* stream);
-/* mode 0 of sbr_adam_rows for the rows step `step` is about to read, in a form that may run beside the optimizer launch of
- * step - 1 (behind the optimizer launch of step - 2 and the previous call of this entry point): rows the catch-up of step - 1
- * claimed (claim_ahead: int32 [n_rows * ceil(D / 64)], zeroed once, this entry point's own) are left to that optimizer launch,
- * the others are replayed up to step - 1 with that step's schedule entry evaluated from the arguments. Requires that step - 1's
- * optimizer launch gets the ids its catch-up got. train/trainer.py:204-223 orders nothing here: only this step's user lookup
- * reads the rows (new in ABI 3). */
-int sbr_adam_rows_catch_up_ahead(int kind, float* p, float* m, float* v, long n_rows, int D, const long* ids64, const int* ids32,
-                                 const int* rowmap, long n, int* claim_ahead, int* last, const void* sched, double lr, double b1,
-                                 double b2, double eps, double wd, long step, void* stream);
 /* optimizer.step() + zero_grad() of a step whose flat buffers (n elements) hold ONE deferred table in [lo, hi): mode 1 of
  * sbr_adam_rows for the table's rows named by ids and sbr_adam_step_zero_grad for every other element, in one launch; rows of the
  * table that received no gradient are not touched (new in ABI 3). */

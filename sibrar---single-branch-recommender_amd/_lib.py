@@ -146,27 +146,6 @@ class pin_stream:
         return False
 
 
-class on_stream:
-    """Context manager: make ``torch_stream`` torch's current stream AND the handle ``stream()`` returns — a forked branch of a
-    fused step (the caller orders it against the other stream with ``wait_stream`` on both sides; inside a graph capture those
-    become the branch's fork and join edges)."""
-
-    def __init__(self, torch_stream):
-        self.s = torch_stream
-
-    def __enter__(self):
-        import torch
-        self.ctx = torch.cuda.stream(self.s)
-        self.ctx.__enter__()
-        self.prev = _STREAM.value
-        _STREAM.value = self.s.cuda_stream
-        return self.s
-
-    def __exit__(self, *exc):
-        _STREAM.value = self.prev
-        return self.ctx.__exit__(*exc)
-
-
 def to_device(t, device):
     """Host -> device copy that is asynchronous only for PINNED sources. An "async" copy from pageable memory may read the
     host buffer after the call returned (observed on ROCm: a temporary staging tensor was recycled before its copy ran — garbage

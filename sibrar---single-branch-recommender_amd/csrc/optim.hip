@@ -67,15 +67,11 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
 // one L2 round trip per replayed step for sched[s]: a wave now fetches the schedule of up to 64 steps with ONE load (lane i holds
 // step s0 + 1 + i) and broadcasts an entry per step with v_readlane; the loop is unrolled by four so that the square roots and
 // divisions of neighbouring steps (which depend on the moments only, not on the parameter) overlap.
-// (s_over, over): the schedule entry of step s_over comes from the arguments instead of the table (-1: none) — the catch-up that
-// runs AHEAD of the previous step's optimizer launch, which is what writes that entry
 __device__ __forceinline__ void adam_replay(float& pe, float& me, float& ve, int s_from, int s_to, const float2* __restrict__ sched,
-                                            const AdamHyper& h, float zero, int lane, int s_over = -1,
-                                            float2 over = make_float2(1.f, 1.f)) {
+                                            const AdamHyper& h, float zero, int lane) {
   for (int base = s_from; base <= s_to; base += 64) {                 // s_from / s_to are wave-uniform
     const int cnt = s_to - base + 1 < 64 ? s_to - base + 1 : 64;
-    float2 mine = lane < cnt && base + lane != s_over ? sched[base + lane] : make_float2(1.f, 1.f);
-    if (base + lane == s_over) mine = over;
+    const float2 mine = lane < cnt ? sched[base + lane] : make_float2(1.f, 1.f);
     const int sx = __float_as_int(mine.x), sy = __float_as_int(mine.y);
     int i = 0;
     for (; i + 4 <= cnt; i += 4) {
@@ -101,20 +97,16 @@ __device__ __forceinline__ void adam_subrow(float* __restrict__ p, float* __rest
   const int r = rowmap ? rowmap[id] : (int)id;
   if (r < 0) return;                                          // id without a row: flagged by the lookup kernel
   const long q = (long)r * n_sub + sub;
-  // mode 3 (catch-up AHEAD): the launch may run beside step t - 1's optimizer launch. claim = a SECOND array (tokens = t of the
-  // catch-up launches only): the row was read by step t - 1 iff that step's catch-up claimed it — it then gets its gradient and is
-  // brought to t - 1 by that optimizer launch, done or not: nothing to do here. Every other row is touched by nobody else.
-  const int token = mode == 3 ? t : 2 * t - 1 + mode;
+  const int token = 2 * t - 1 + mode;
   int old = 0;
   if (lane == 0) old = atomicMax(&claim[q], token);
   old = __builtin_amdgcn_readfirstlane(old);
   if (old >= token) return;                                   // another wave of this launch owns the sub-row
-  if (mode == 3 && old == t - 1) return;
   const int s0 = __builtin_amdgcn_readfirstlane(last[q]);
   const int c = sub * 64 + lane;
   const long e = (long)r * D + (c < D ? c : D - 1);
   float pe = p[e], me = m[e], ve = v[e];
-  adam_replay(pe, me, ve, s0 + 1, t - 1, sched, h, zero, lane, mode == 3 ? t - 1 : -1, make_float2(step_size, bc2_sqrt));
+  adam_replay(pe, me, ve, s0 + 1, t - 1, sched, h, zero, lane);
   if (mode == 1) adam_element(pe, g[e], me, ve, h, step_size, bc2_sqrt);
   if (c < D) {
     p[e] = pe;
@@ -251,37 +243,6 @@ extern "C" int sbr_adam_step_zero_grad(int kind, float* p, float* g, float* m, f
 // their gradient rows, zero those gradient rows and record the step's scalars in sched[step]; mode 2: flush all rows to `step`.
 // claim / last: int32 [n_rows * ceil(D / 64)] (one entry per 64-element sub-row), zero-initialised by the caller;
 // sched: float2 [>= step + 1].
-// The catch-up of sbr_adam_rows (mode 0) for the rows step `step` is about to read, in a form that may run BESIDE the optimizer launch
-// of step - 1 (sbr_adam_step_rows with the ids of THAT step) and the whole of step - 1 behind its own catch-up; it must run after the
-// optimizer launch of step - 2 and after the previous launch of this entry point. claim_ahead: int32 [n_rows * ceil(D / 64)], zeroed
-// once, used by this entry point only (step numbers): a sub-row claimed by the catch-up of step - 1 is left to that step's
-// optimizer launch; every other row of `ids` is replayed up to step - 1 with the schedule entry of step - 1 taken from the
-// arguments (the optimizer launch that records it may not have run yet). Requires: the ids given to step - 1's optimizer launch
-// are the ids given to step - 1's catch-up (one GPU, or a dense gradient exchange).
-extern "C" int sbr_adam_rows_catch_up_ahead(int kind, float* p, float* m, float* v, long n_rows, int D, const long* ids64, const int* ids32,
-                                            const int* rowmap, long n, int* claim_ahead, int* last, const void* sched, double lr,
-                                            double b1, double b2, double eps, double wd, long step, void* stream) {
-  SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_rows_catch_up_ahead: unknown kind %d", kind);
-  SBR_REQUIRE(p && m && v && claim_ahead && last && sched && (ids64 || ids32) && D >= 1 && n_rows >= 0, "sbr_adam_rows_catch_up_ahead: null operand");
-  SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_rows_catch_up_ahead: step %ld out of range", step);
-  if (n <= 0) return SBR_OK;
-  const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
-  float* zero = nullptr;
-  if (hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(sbr_adam_zero)) != hipSuccess) {
-    sbr_set_error("sbr_adam_rows_catch_up_ahead: hipGetSymbolAddress failed");
-    return SBR_ERR_HIP;
-  }
-  // the scalars of step - 1, as its optimizer launch evaluates them
-  const double bc1 = step > 1 ? 1.0 - pow(b1, (double)(step - 1)) : 1.0;
-  const double bc2 = step > 1 ? 1.0 - pow(b2, (double)(step - 1)) : 1.0;
-  const int n_sub = (D + 63) / 64;
-  adam_rows_kernel<<<sbr_cdiv(n * n_sub, 4), 256, 0, (hipStream_t)stream>>>(p, nullptr, m, v, D, n_sub, ids64, ids32, rowmap, n, claim_ahead, last,
-                                                                           (float2*)const_cast<void*>(sched), (int)step, h, (float)(lr / bc1),
-                                                                           (float)sqrt(bc2), zero, 3);
-  SBR_CHECK_LAUNCH("sbr_adam_rows_catch_up_ahead");
-  return SBR_OK;
-}
-
 extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, long n_rows, int D, const long* ids64,
                              const int* ids32, const int* rowmap, long n, int* claim, int* last, void* sched, double lr, double b1,
                              double b2, double eps, double wd, long step, void* stream) {

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from ._lib import call, on_stream, pin_stream, ptr, to_device
+from ._lib import call, pin_stream, ptr, to_device
 from .config import EmbeddingRegularizationType
 from .losses import RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy, RecSampledSoftmaxLoss
 from .sbnet import FeatureEmbedding, SingleBranchNet, SingleBranchNetEntity, resolve_rows
@@ -486,8 +486,6 @@ class DeferredTable:
         self.last = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
         self.claim = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
         self.sched = torch.zeros(4096, 2, device=dev, dtype=torch.float32)
-        self._sched_retired = []     # outgrown schedules: a catch-up queued on the side stream may still read the old block
-        self.claim_ahead = None      # claims of catch_up_ahead (its own array: see sbr_adam_rows_catch_up_ahead)
         self.kind = 0 if opt.name == 'adamw' else 1
         self.flushed_to = 0          # step up to which EVERY row is known to be current
         if opt.step_count > 0:       # steps taken densely before this object existed: every row is current
@@ -498,7 +496,6 @@ class DeferredTable:
         if step >= self.sched.shape[0]:
             bigger = torch.zeros(2 * max(step, self.sched.shape[0]), 2, device=self.sched.device, dtype=torch.float32)
             bigger[:self.sched.shape[0]] = self.sched
-            self._sched_retired.append(self.sched)
             self.sched = bigger
 
     @staticmethod
@@ -519,20 +516,6 @@ class DeferredTable:
         """ids: the entity ids (int64, mapped through the table's id map) or table rows (int32) the coming step reads."""
         if self.opt.step_count > self.flushed_to:
             self._call(0, ids, self.opt.step_count + 1)
-
-    def catch_up_ahead(self, ids: torch.Tensor):
-        """``catch_up`` in the form that may run beside the previous step's optimizer launch (``sbr_adam_rows_catch_up_ahead``): the
-        caller queues it on a second stream behind the optimizer launch of the step BEFORE the previous one, and only while every
-        step's ``step(ids)`` gets the ids its catch-up got."""
-        step = self.opt.step_count + 1
-        self._grow_sched(step)
-        if self.claim_ahead is None:
-            self.claim_ahead = torch.zeros_like(self.claim)
-        ids64, ids32 = self._ids(ids)
-        o = self.opt
-        call('sbr_adam_rows_catch_up_ahead', self.kind, ptr(self.p), ptr(self.m), ptr(self.v), self.n_rows, self.D, ptr(ids64), ptr(ids32),
-             ptr(self.rowmap) if ids64 is not None else None, ids.numel(), ptr(self.claim_ahead), ptr(self.last), ptr(self.sched),
-             float(o.lr), 0.9, 0.999, 1e-8, float(o.wd), int(step), ops.stream())
 
     def update(self, ids: torch.Tensor):
         """Apply step ``opt.step_count`` (already counted) to the rows that received gradient; zeroes those gradient rows."""
@@ -622,10 +605,6 @@ class FusedTrainStep:
         # at the reference's batch 256 — leave the optimizer's HBM stream (c2: 358 of 541 MB per step). One extra launch per step
         # (the catch-up of the rows a batch reads); the update rides on the optimizer launch (sbr_adam_step_rows).
         self.deferred = None
-        # catch-up of a row-wise updated table AHEAD of the previous step's optimizer launch, on a second stream (_catch_up)
-        self._side = None
-        self._ev_opt = [None, None]  # events behind the optimizer launches of the last two steps (by step parity)
-        self._ahead_at = -2          # n_steps of the last step whose catch-up used the ahead form
         fe = net.user_embedding_module
         if (isinstance(self.user, _PlainRun) and fe.kind == 'categorical' and self._urange is not None
                 and optimizer.name in ('adamw', 'adam') and optimizer.deferred is None
@@ -896,7 +875,7 @@ class FusedTrainStep:
                 if self._sparse is False and self.deferred is not None:       # dense all-reduce: touched rows unknown
                     self._drop_deferred()
             if self.deferred is not None:
-                self._catch_up(pb, native)                                   # the rows this step's forward pass reads
+                self.deferred.catch_up(pb.u[:-1])                            # the rows this step's forward pass reads
             if self.use_graph and pb.pi[5] and not ops.KernelTimer.enabled:
                 if self._arena_buf is not self.arena.buf:            # the arena moved: captured addresses are stale
                     self._graphs.clear()
@@ -938,50 +917,12 @@ class FusedTrainStep:
             # with a deferred lookup table the same launch updates it row by row: only the rows that received gradient are touched
             rows = None if self.deferred is None else (self._touched_rows if self._sparse else pb.u[:-1])
             took = self.opt.step_flat(zero_grad=True, copy=cp, rows=rows)
-            if self.deferred is not None:
-                ev = self._ev_opt[self.n_steps & 1]
-                if ev is None:
-                    ev = self._ev_opt[self.n_steps & 1] = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
             if static is not None:
                 self.last_out3 = fresh if took else static.clone()   # (total, rec, reg) of this step as one [3] tensor
                 out = self.last_out3.unbind(0)
             if native is not None:
                 native[0].release(native[1])                         # everything queued so far has read the slot
             return out
-
-    # the replay arithmetic of a batch below this many table elements is not worth a second stream's host calls
-    AHEAD_MIN_ELEMENTS = 1 << 18
-
-    def _catch_up(self, pb, native):
-        """Brings the rows this step reads up to date. The replay is a dependent chain per element (as long as the row has been
-        idle): ~60 us at c2 that fill no pipe. Nothing but this step's lookup needs its result, and it needs nothing newer than the
-        optimizer launch of the step BEFORE the previous one (rows of the previous batch are left to the previous optimizer launch):
-        queued on a second stream behind that launch, it runs beside the previous step's backward pass and optimizer launch whenever
-        the host is a step ahead of the GPU. One process / dense exchange only (the optimizer's ids must be the catch-up's)."""
-        d = self.deferred
-        ids = pb.u[:-1]
-        if self._sparse is not False or ids.numel() * d.D < self.AHEAD_MIN_ELEMENTS:
-            d.catch_up(ids)
-            return
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=ids.device)
-        side = self._side
-        prev2 = self._ev_opt[self.n_steps & 1]                        # recorded by step n_steps - 2
-        if self._ahead_at == self.n_steps - 1 and prev2 is not None:
-            side.wait_event(prev2)
-        else:
-            side.wait_stream(main)                                       # the previous catch-up was not of this form: no overlap
-        with on_stream(side):
-            if native is not None:
-                native[0].wait(native[1])
-            if pb.event is not None:
-                side.wait_event(pb.event)
-                ids.record_stream(side)
-            d.catch_up_ahead(ids)
-        main.wait_stream(side)
-        self._ahead_at = self.n_steps
 
     def flush(self):
         """Bring a row-wise updated table up to date (no-op otherwise). Called automatically before state_dict(), the user

@@ -546,11 +546,8 @@ def test_fused_step_with_deferred_row_wise_adam_equals_dense_optimizer(optimizer
            'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'item_embedding'}],
                     'single_branch_hidden_layers': [32], 'preference_hidden_layers': [], 'common_modality_dim': 32}}
     runs = []
-    # third run: the catch-up in its AHEAD form on the second stream (engine.FusedTrainStep._catch_up; forced on for this small
-    # batch), beside the previous step's optimizer launch: rows of the previous batch are left to that launch
-    for deferred, ahead in (('0', False), ('1', False), ('1', True)):
+    for deferred in ('0', '1'):
         monkeypatch.setenv('SBR_DEFERRED_ADAM', deferred)
-        monkeypatch.setattr(S.FusedTrainStep, 'AHEAD_MIN_ELEMENTS', 0 if ahead else 1 << 62)
         torch.manual_seed(11)
         np.random.seed(11)
         net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(cfg), ds).to(DEV)
@@ -570,19 +567,17 @@ def test_fused_step_with_deferred_row_wise_adam_equals_dense_optimizer(optimizer
             losses.append(torch.stack(fused.step(u, i, labels)).cpu())
             if s_ == 12:
                 mid = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-        assert (fused._ahead_at == fused.n_steps) == ahead
         fused.close()
         lo, hi = fused._urange
         runs.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
                      opt.m[lo:hi].cpu().clone(), opt.v[lo:hi].cpu().clone(), mid))
     key = 'user_embedding_module.embedding_layer.weight'
-    for r, name in ((1, 'deferred'), (2, 'deferred, catch-up ahead')):
-        close(runs[r][1][key], runs[0][1][key], what=f'user table ({name})', rtol=1e-4, atol=1e-5)
-        close(runs[r][4][key], runs[0][4][key], what=f'user table at the mid-run flush ({name})', rtol=1e-4, atol=1e-5)
-        close(runs[r][2], runs[0][2], what=f'first moments ({name})', rtol=1e-4, atol=1e-6)
-        close(runs[r][3], runs[0][3], what=f'second moments ({name})', rtol=1e-4, atol=1e-8)
-        for s_, (a_, b_) in enumerate(zip(runs[0][0], runs[r][0])):
-            close(b_, a_, what=f'losses step {s_} ({name})', rtol=1e-5, atol=1e-8)
+    close(runs[1][1][key], runs[0][1][key], what='user table', rtol=1e-4, atol=1e-5)
+    close(runs[1][4][key], runs[0][4][key], what='user table at the mid-run flush', rtol=1e-4, atol=1e-5)
+    close(runs[1][2], runs[0][2], what='first moments', rtol=1e-4, atol=1e-6)
+    close(runs[1][3], runs[0][3], what='second moments', rtol=1e-4, atol=1e-8)
+    for s_, (a_, b_) in enumerate(zip(runs[0][0], runs[1][0])):
+        close(b_, a_, what=f'losses step {s_}', rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.gpu

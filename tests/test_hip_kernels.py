@@ -731,65 +731,6 @@ def test_deferred_row_wise_adam_replay_is_bit_identical(name):
     assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
 
 
-@pytest.mark.parametrize('name', ['adamw', 'adam'])
-def test_deferred_adam_catch_up_ahead_of_the_previous_optimizer_launch_is_bit_identical(name):
-    """sbr_adam_rows_catch_up_ahead as engine.FusedTrainStep._catch_up queues it: on a second stream, behind the optimizer launch of
-    the step BEFORE the previous one — so it runs before, beside or after the previous step's optimizer launch (sbr_adam_step_rows;
-    odd steps delay that launch with a spin kernel so that the catch-up really overtakes it). Rows of the previous batch are
-    left to that launch, every other row is replayed with the previous step's schedule entry taken from the arguments. 40 steps with
-    deterministic gradients, batches that share rows with their predecessors, duplicate ids, an id map: parameters and moments end
-    BIT-identical to the dense optimizer stepping the whole table every step (train/trainer.py:62-68)."""
-    import sibrar_amd as S
-    from importlib import import_module
-    pkg = S.ops.__name__.rsplit('.', 1)[0]
-    engine, _lib = import_module(pkg + '.engine'), import_module(pkg + '._lib')
-    R, D = 300, 80                                                    # two sub-rows per row, the second one ragged
-    g = torch.Generator().manual_seed(6)
-    w0 = torch.randn(R, D, generator=g) * 0.1
-    rowmap = torch.randperm(R, generator=g).to(torch.int32)
-    mods, opts = [], []
-    for _ in range(2):
-        m = torch.nn.Embedding(R, D)
-        with torch.no_grad():
-            m.weight.copy_(w0)
-        m.to(DEV)
-        mods.append(m)
-        opts.append(S.FusedOptimizer(m, name, lr=3e-3, weight_decay=1e-2))
-        opts[-1].zero_grad()
-    d = engine.DeferredTable(opts[1], mods[1].weight, 0, R * D, rowmap.to(DEV))
-    opts[1].deferred = d
-    rng = np.random.default_rng(3)
-    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
-    evs = [torch.cuda.Event(), torch.cuda.Event()]
-    plan = []
-    for t in range(40):
-        n = int(rng.integers(1, 12))
-        ids = torch.from_numpy(rng.integers(0, R if t % 7 else 6, size=n))          # entity ids: duplicates, overlap with step t - 1
-        rows = rowmap[ids].long().unique()
-        plan.append((ids.to(DEV), rows.to(DEV), torch.randn(len(rows), D, generator=g).to(DEV)))
-    torch.cuda.synchronize()                                                      # every upload done: no host sync in the loop
-    for t, (ids_dev, rows_dev, grad_rows) in enumerate(plan):
-        opts[0].zero_grad()
-        mods[0].weight.grad[rows_dev] = grad_rows
-        opts[0].step_flat()
-        # ---- the deferred table, as FusedTrainStep.step orders it
-        if t >= 2:
-            side.wait_event(evs[t & 1])                                           # the optimizer launch of step t - 2
-        with _lib.on_stream(side):
-            d.catch_up_ahead(ids_dev)
-        main.wait_stream(side)
-        mods[1].weight.grad[rows_dev] = grad_rows                                 # "backward pass"
-        if t % 2:
-            torch.cuda._sleep(20_000_000)                                         # the next catch-up overtakes this optimizer launch
-        assert opts[1].step_flat(zero_grad=True, rows=ids_dev) is False
-        evs[t & 1].record(main)
-    torch.cuda.synchronize()
-    assert float(mods[1].weight.grad.abs().max()) == 0.0
-    d.flush()
-    assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
-    assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
-
-
 @pytest.mark.parametrize('W,Bu,k', [(1, 5, 3), (2, 300, 20), (8, 1000, 20), (8, 77, 32), (4, 50, 1)])
 def test_merge_topk_kernel_equals_the_host_merge(W, Bu, k):
     """sbr_merge_topk (item-sharded evaluation: the all-gathered per-shard lists) == parallel.merge_topk (torch formulation, pinned
