@@ -368,10 +368,15 @@ int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, float* v, lo
                   double wd, long step, void* stream);
 /* optimizer.step() + zero_grad() of a step whose flat buffers (n elements) hold ONE deferred table in [lo, hi): mode 1 of
  * sbr_adam_rows for the table's rows named by ids and sbr_adam_step_zero_grad for every other element, in one launch; rows of the
- * table that received no gradient are not touched (new in ABI 3). */
+ * table that received no gradient are not touched — except the n_sweep sub-rows (64-element pieces of rows, in table order) from
+ * sweep_lo on, cyclically, which are brought up to `step` beside the dense part's memory stream: a caller that sweeps 1 / W of the
+ * table per step bounds every row's backlog — the length of a catch-up or flush replay — by W steps. n_sweep > 0 requires that
+ * the step's catch-up (sbr_adam_rows mode 0 with the same ids and step) ran before: the sweep recognises the batch's rows by its
+ * claims and leaves them to their update (new in ABI 3). */
 int sbr_adam_step_rows(int kind, float* p, float* g, float* m, float* v, long n, long lo, long hi, int D, const long* ids64,
                        const int* ids32, const int* rowmap, long n_ids, int* claim, int* last, void* sched, double lr, double b1,
-                       double b2, double eps, double wd, long step, const double* copy_src, double* copy_dst, int copy_n, void* stream);
+                       double b2, double eps, double wd, long step, long sweep_lo, long n_sweep, const double* copy_src,
+                       double* copy_dst, int copy_n, void* stream);
 int sbr_adagrad_step(float* p, const float* g, float* state_sum, long n, double lr, double eps, double wd, void* stream);
 
 /* ---- full-catalogue evaluation — eval/eval.py:205-222 ------------------------------------------------------------------------

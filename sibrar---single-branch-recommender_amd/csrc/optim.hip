@@ -67,11 +67,15 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
 // one L2 round trip per replayed step for sched[s]: a wave now fetches the schedule of up to 64 steps with ONE load (lane i holds
 // step s0 + 1 + i) and broadcasts an entry per step with v_readlane; the loop is unrolled by four so that the square roots and
 // divisions of neighbouring steps (which depend on the moments only, not on the parameter) overlap.
+// (s_over, over): the schedule entry of step s_over comes from the arguments instead of the table (-1: none) — the launch that
+// records the entry of its own step replays that step for the rows of its sweep
 __device__ __forceinline__ void adam_replay(float& pe, float& me, float& ve, int s_from, int s_to, const float2* __restrict__ sched,
-                                            const AdamHyper& h, float zero, int lane) {
+                                            const AdamHyper& h, float zero, int lane, int s_over = -1,
+                                            float2 over = make_float2(1.f, 1.f)) {
   for (int base = s_from; base <= s_to; base += 64) {                 // s_from / s_to are wave-uniform
     const int cnt = s_to - base + 1 < 64 ? s_to - base + 1 : 64;
-    const float2 mine = lane < cnt ? sched[base + lane] : make_float2(1.f, 1.f);
+    float2 mine = lane < cnt && base + lane != s_over ? sched[base + lane] : make_float2(1.f, 1.f);
+    if (base + lane == s_over) mine = over;
     const int sx = __float_as_int(mine.x), sy = __float_as_int(mine.y);
     int i = 0;
     for (; i + 4 <= cnt; i += 4) {
@@ -152,29 +156,70 @@ __global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict_
   if (lane == 0) last[q] = t;
 }
 
-// The optimizer launch of a step whose flat buffers hold one deferred table in [lo, hi): workgroups [0, row_blocks) apply step t to
-// the sub-rows that received gradient (mode 1 of adam_subrow, four waves each), the rest run the dense kernel (with the gradient
-// reset and the loss read-out of adamw_kernel<true>) over [0, lo) and [hi, n): ONE launch for optimizer.step() + zero_grad().
+// The optimizer launch of a step whose flat buffers hold one deferred table in [lo, hi): ONE launch for optimizer.step() +
+// zero_grad(). Three kinds of workgroups:
+//   rows   [row_blocks]: step t for the sub-rows that received gradient (mode 1 of adam_subrow, four waves each);
+//   sweep  [sweep_blocks]: the sub-rows [sweep_lo, sweep_lo + n_sweep) (mod the table) that are NOT in this step's batch are brought
+//          up to step t. The sweep visits every sub-row once in W steps, so no row is ever more than W steps behind: the catch-up in
+//          front of a forward pass replays at most W steps per row (not ~n_rows / batch), and a flush W steps per row, not a whole
+//          epoch's. The replay arithmetic is what it is (one zero-gradient step per row and step, as in the dense optimizer); here it
+//          runs beside the HBM stream of the dense part. A sub-row of this step's batch is recognised by the claim its catch-up
+//          left (token 2 t - 1, or the 2 t of its update wave): the sweep leaves it to the update wave.
+//   dense: the dense kernel (gradient reset and loss read-out of adamw_kernel<true>) over [0, lo) and [hi, n).
+// Dense and row/sweep workgroups alternate in the grid so that the arithmetic of the one overlaps the memory stream of the other.
 __global__ __launch_bounds__(256) void adam_step_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                              float* __restrict__ v, long n, long lo, long hi, int D, int n_sub,
                                                              const long* __restrict__ ids64, const int* __restrict__ ids32,
                                                              const int* __restrict__ rowmap, long n_ids, int* __restrict__ claim,
                                                              int* __restrict__ last, float2* __restrict__ sched, int t, AdamHyper h,
                                                              float step_size, float bc2_sqrt, const float* __restrict__ zero_src,
-                                                             int row_blocks, const double* __restrict__ cp_src, double* __restrict__ cp_dst,
-                                                             int cp_n) {
-  if ((int)blockIdx.x < row_blocks) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) sched[t] = make_float2(step_size, bc2_sqrt);
-    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
-    if (w < n_ids * n_sub)
-      adam_subrow(p + lo, g + lo, m + lo, v + lo, D, n_sub, ids64, ids32, rowmap, w, claim, last, sched, t, h, step_size, bc2_sqrt, zero_src[0], 1,
-                  threadIdx.x & 63);
+                                                             int row_blocks, int sweep_blocks, long sweep_lo, long n_sweep,
+                                                             const double* __restrict__ cp_src, double* __restrict__ cp_dst, int cp_n) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) sched[t] = make_float2(step_size, bc2_sqrt);        // read by later launches only
+    if ((int)threadIdx.x < cp_n) cp_dst[threadIdx.x] = cp_src[threadIdx.x];
+  }
+  const int n_alu = row_blocks + sweep_blocks, n_dense = (int)gridDim.x - n_alu;
+  const int pair = n_alu < n_dense ? n_alu : n_dense;
+  const int b = (int)blockIdx.x;
+  bool dense;
+  int idx;
+  if (b < 2 * pair) { dense = (b & 1) == 0; idx = b >> 1; }
+  else { dense = n_dense > n_alu; idx = b - pair; }
+  if (!dense) {
+    const int lane = threadIdx.x & 63;
+    if (idx < row_blocks) {
+      const long w = idx * 4L + (threadIdx.x >> 6);
+      if (w < n_ids * n_sub)
+        adam_subrow(p + lo, g + lo, m + lo, v + lo, D, n_sub, ids64, ids32, rowmap, w, claim, last, sched, t, h, step_size, bc2_sqrt, zero_src[0], 1, lane);
+      return;
+    }
+    const long w = (idx - row_blocks) * 4L + (threadIdx.x >> 6);
+    if (w >= n_sweep) return;
+    const long n_q = (hi - lo) / D * n_sub;
+    long q = sweep_lo + w;
+    q = q >= n_q ? q - n_q : q;
+    int old = 0;
+    if (lane == 0) old = atomicMax(&claim[q], 2 * t - 1);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old >= 2 * t - 1) return;                               // a sub-row of this step's batch: its update wave owns it
+    const int s0 = __builtin_amdgcn_readfirstlane(last[q]);
+    if (s0 >= t) return;
+    const long r = q / n_sub;
+    const int c = (int)(q - r * n_sub) * 64 + lane;
+    const long e = lo + r * D + (c < D ? c : D - 1);
+    float pe = p[e], me = m[e], ve = v[e];
+    adam_replay(pe, me, ve, s0 + 1, t, sched, h, zero_src[0], lane, t, make_float2(step_size, bc2_sqrt));
+    if (c < D) {
+      p[e] = pe;
+      m[e] = me;
+      v[e] = ve;
+    }
+    if (lane == 0) last[q] = t;
     return;
   }
-  const long b = blockIdx.x - row_blocks, nb = gridDim.x - row_blocks;
-  if (b == 0 && (int)threadIdx.x < cp_n) cp_dst[threadIdx.x] = cp_src[threadIdx.x];
-  const long span = hi - lo, n_dense = n - span;
-  for (long d = b * (long)blockDim.x + threadIdx.x; d < n_dense; d += nb * blockDim.x) {
+  const long span = hi - lo, n_rest = n - span;
+  for (long d = idx * (long)blockDim.x + threadIdx.x; d < n_rest; d += (long)n_dense * blockDim.x) {
     const long e = d < lo ? d : d + span;
     float pe = p[e], me = m[e], ve = v[e];
     const float ge = g[e];
@@ -277,16 +322,23 @@ extern "C" int sbr_adam_rows(int kind, int mode, float* p, float* g, float* m, f
 
 // optimizer.step() + zero_grad() of a step with ONE deferred table in one launch: the flat buffers p / g / m / v of n elements hold
 // the table in [lo, hi) (hi - lo = n_rows * D); its rows named by ids get mode 1 of sbr_adam_rows, every other element the dense step
-// of sbr_adam_step_zero_grad (gradient reset, copy_n doubles copy_src -> copy_dst). Untouched rows of the table are not read.
+// of sbr_adam_step_zero_grad (gradient reset, copy_n doubles copy_src -> copy_dst). Untouched rows of the table are not read —
+// except the n_sweep sub-rows from sweep_lo on (cyclic), which are brought up to `step` (see the kernel); n_sweep > 0 REQUIRES that the
+// step's catch-up (sbr_adam_rows mode 0, same ids, same step) ran before: its claims are how the sweep tells the batch's rows.
 extern "C" int sbr_adam_step_rows(int kind, float* p, float* g, float* m, float* v, long n, long lo, long hi, int D, const long* ids64,
                                   const int* ids32, const int* rowmap, long n_ids, int* claim, int* last, void* sched, double lr,
-                                  double b1, double b2, double eps, double wd, long step, const double* copy_src, double* copy_dst,
-                                  int copy_n, void* stream) {
+                                  double b1, double b2, double eps, double wd, long step, long sweep_lo, long n_sweep,
+                                  const double* copy_src, double* copy_dst, int copy_n, void* stream) {
   SBR_REQUIRE(kind == 0 || kind == 1, "sbr_adam_step_rows: unknown kind %d", kind);
   SBR_REQUIRE(p && g && m && v && claim && last && sched && (ids64 || ids32 || n_ids == 0), "sbr_adam_step_rows: null operand");
   SBR_REQUIRE(0 <= lo && lo <= hi && hi <= n && D >= 1 && (hi - lo) % D == 0, "sbr_adam_step_rows: bad table range [%ld, %ld) of %ld, D = %d", lo, hi, n, D);
   SBR_REQUIRE(step >= 1 && step < (1L << 30), "sbr_adam_step_rows: step %ld out of range", step);
   SBR_REQUIRE(copy_n >= 0 && copy_n <= 256 && (copy_n == 0 || (copy_src && copy_dst)), "sbr_adam_step_rows: bad copy request");
+  {
+    const long n_q = (hi - lo) / D * ((D + 63) / 64);
+    SBR_REQUIRE(n_sweep >= 0 && n_sweep <= n_q && (n_sweep == 0 || (sweep_lo >= 0 && sweep_lo < n_q)),
+                "sbr_adam_step_rows: bad sweep [%ld, +%ld) of %ld sub-rows", sweep_lo, n_sweep, n_q);
+  }
   const AdamHyper h = adam_hyper(lr, b1, b2, eps, wd, kind == 0);
   float* zero = nullptr;
   if (hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(sbr_adam_zero)) != hipSuccess) {
@@ -296,11 +348,12 @@ extern "C" int sbr_adam_step_rows(int kind, float* p, float* g, float* m, float*
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
   const int n_sub = (D + 63) / 64;
-  const int row_blocks = n_ids > 0 ? sbr_cdiv(n_ids * n_sub, 4) : 1;       // block 0 records sched[step] even without rows
-  const int dense_blocks = grid_for(n - (hi - lo));
-  adam_step_rows_kernel<<<row_blocks + dense_blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lo, hi, D, n_sub, ids64, ids32, rowmap, n_ids, claim,
-                                                                                    last, (float2*)sched, (int)step, h, (float)(lr / bc1),
-                                                                                    (float)sqrt(bc2), zero, row_blocks, copy_src, copy_dst, copy_n);
+  const int row_blocks = n_ids > 0 ? sbr_cdiv(n_ids * n_sub, 4) : 0;
+  const int sweep_blocks = sbr_cdiv(n_sweep, 4);
+  const int dense_blocks = grid_for(n - (hi - lo));             // >= 1: block 0 records sched[step] and makes the copy in any case
+  adam_step_rows_kernel<<<row_blocks + sweep_blocks + dense_blocks, 256, 0, (hipStream_t)stream>>>(
+      p, g, m, v, n, lo, hi, D, n_sub, ids64, ids32, rowmap, n_ids, claim, last, (float2*)sched, (int)step, h, (float)(lr / bc1), (float)sqrt(bc2), zero,
+      row_blocks, sweep_blocks, sweep_lo, n_sweep, copy_src, copy_dst, copy_n);
   SBR_CHECK_LAUNCH("sbr_adam_step_rows");
   return SBR_OK;
 }

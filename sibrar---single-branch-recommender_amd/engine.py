@@ -474,6 +474,8 @@ class DeferredTable:
     ``flush`` before anybody else reads the table: the model's state_dict, its module-level forward (evaluation, autograd path), a
     dense optimizer step, ``FusedTrainStep.close``."""
 
+    SWEEP_EVERY = 16                 # every row is brought up to date at least every SWEEP_EVERY steps (0: no sweep)
+
     def __init__(self, opt, param: torch.Tensor, lo: int, hi: int, rowmap: Optional[torch.Tensor]):
         n_rows, D = param.shape
         assert param.stride() == (D, 1) and hi - lo == n_rows * D
@@ -486,6 +488,11 @@ class DeferredTable:
         self.last = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
         self.claim = torch.zeros(n_rows * n_sub, device=dev, dtype=torch.int32)
         self.sched = torch.zeros(4096, 2, device=dev, dtype=torch.float32)
+        # the sweep of the optimizer launch (csrc/optim.hip, adam_step_rows_kernel): 1 / SWEEP_EVERY of the table's sub-rows per step
+        self.n_q = n_rows * n_sub
+        self._cursor = 0
+        self._caught = -1            # step whose catch-up has run (its claims are how the sweep tells that step's rows)
+        self.sweep_ok = True         # False: the optimizer's ids are not the catch-up's (sparse data-parallel exchange)
         self.kind = 0 if opt.name == 'adamw' else 1
         self.flushed_to = 0          # step up to which EVERY row is known to be current
         if opt.step_count > 0:       # steps taken densely before this object existed: every row is current
@@ -514,8 +521,8 @@ class DeferredTable:
 
     def catch_up(self, ids: torch.Tensor):
         """ids: the entity ids (int64, mapped through the table's id map) or table rows (int32) the coming step reads."""
-        if self.opt.step_count > self.flushed_to:
-            self._call(0, ids, self.opt.step_count + 1)
+        self._call(0, ids, self.opt.step_count + 1)
+        self._caught = self.opt.step_count + 1
 
     def update(self, ids: torch.Tensor):
         """Apply step ``opt.step_count`` (already counted) to the rows that received gradient; zeroes those gradient rows."""
@@ -531,10 +538,16 @@ class DeferredTable:
         ids64, ids32 = self._ids(ids)
         src, dst = copy if copy is not None else (None, None)
         fp = o.fp
+        # the sweep needs the claims of this step's catch-up (same ids) to tell the batch's rows from the others
+        n_sweep = 0
+        if self.SWEEP_EVERY > 0 and self.sweep_ok and self._caught == o.step_count:
+            n_sweep = -(-self.n_q // self.SWEEP_EVERY)
+        sweep_lo = self._cursor
+        self._cursor = (self._cursor + n_sweep) % self.n_q
         call('sbr_adam_step_rows', self.kind, ptr(fp.flat), ptr(fp.grad), ptr(o.m), ptr(o.v), fp.total, self.lo, self.hi, self.D, ptr(ids64),
              ptr(ids32), ptr(self.rowmap) if ids64 is not None else None, 0 if ids is None else ids.numel(), ptr(self.claim),
-             ptr(self.last), ptr(self.sched), float(o.lr), 0.9, 0.999, 1e-8, float(o.wd), int(o.step_count), ptr(src), ptr(dst),
-             0 if src is None else src.numel(), ops.stream())
+             ptr(self.last), ptr(self.sched), float(o.lr), 0.9, 0.999, 1e-8, float(o.wd), int(o.step_count), sweep_lo, n_sweep,
+             ptr(src), ptr(dst), 0 if src is None else src.numel(), ops.stream())
         return src is not None
 
     def flush(self):
@@ -916,6 +929,8 @@ class FusedTrainStep:
             cp = (static, fresh) if static is not None else None
             # with a deferred lookup table the same launch updates it row by row: only the rows that received gradient are touched
             rows = None if self.deferred is None else (self._touched_rows if self._sparse else pb.u[:-1])
+            if self.deferred is not None and self._sparse:
+                self.deferred.sweep_ok = False                       # rows of other ranks' batches: not claimed by this rank's catch-up
             took = self.opt.step_flat(zero_grad=True, copy=cp, rows=rows)
             if static is not None:
                 self.last_out3 = fresh if took else static.clone()   # (total, rec, reg) of this step as one [3] tensor

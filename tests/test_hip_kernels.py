@@ -731,6 +731,59 @@ def test_deferred_row_wise_adam_replay_is_bit_identical(name):
     assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
 
 
+@pytest.mark.parametrize('name,every', [('adamw', 4), ('adam', 7), ('adamw', 16)])
+def test_deferred_adam_with_the_sweep_of_the_optimizer_launch_is_bit_identical(name, every):
+    """engine.DeferredTable.step (sbr_adam_step_rows): besides the rows that received gradient, the optimizer launch brings 1 / W of
+    the table's sub-rows per step up to date (cyclic sweep), so that no row is ever more than W steps behind. 60 steps with
+    deterministic gradients, duplicate ids, an id map, rows of two ragged sub-rows, batches that hit the swept range, one step whose
+    catch-up is left out (no sweep then): parameters and moments stay BIT-identical to the dense optimizer stepping the whole
+    table every step (train/trainer.py:62-68), and the backlog of every row stays within W (+ the one step without a sweep)."""
+    import sibrar_amd as S
+    from importlib import import_module
+    engine = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine')
+    R, D = 300, 80
+    g = torch.Generator().manual_seed(8)
+    w0 = torch.randn(R, D, generator=g) * 0.1
+    rowmap = torch.randperm(R, generator=g).to(torch.int32)
+    mods, opts = [], []
+    for _ in range(2):
+        m = torch.nn.Embedding(R, D)
+        with torch.no_grad():
+            m.weight.copy_(w0)
+        m.to(DEV)
+        mods.append(m)
+        opts.append(S.FusedOptimizer(m, name, lr=3e-3, weight_decay=1e-2))
+        opts[-1].zero_grad()
+    d = engine.DeferredTable(opts[1], mods[1].weight, 0, R * D, rowmap.to(DEV))
+    d.SWEEP_EVERY = every
+    opts[1].deferred = d
+    rng = np.random.default_rng(4)
+    for t in range(60):
+        n = int(rng.integers(1, 40))
+        ids = torch.from_numpy(rng.integers(0, R if t % 5 else 8, size=n))
+        rows = rowmap[ids].long().unique().to(DEV)
+        grad_rows = torch.randn(len(rows), D, generator=g).to(DEV)
+        opts[0].zero_grad()
+        mods[0].weight.grad[rows] = grad_rows
+        opts[0].step_flat()
+        ids_dev = ids.to(DEV)
+        if t != 33:
+            d.catch_up(ids_dev)
+        else:                                                        # (rows are current after the flush below: nothing to catch up)
+            d.flush()
+        mods[1].weight.grad[rows] = grad_rows
+        assert opts[1].step_flat(zero_grad=True, rows=ids_dev) is False
+        assert float(mods[1].weight.grad.abs().max()) == 0.0
+        if t >= every + 1:
+            assert int((opts[1].step_count - d.last).max()) <= every + (1 if 33 <= t <= 33 + every else 0), t
+        if t in (20, 41):
+            d.flush()
+            assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu()), t
+    d.flush()
+    assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
+    assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
+
+
 @pytest.mark.parametrize('W,Bu,k', [(1, 5, 3), (2, 300, 20), (8, 1000, 20), (8, 77, 32), (4, 50, 1)])
 def test_merge_topk_kernel_equals_the_host_merge(W, Bu, k):
     """sbr_merge_topk (item-sharded evaluation: the all-gathered per-shard lists) == parallel.merge_topk (torch formulation, pinned

@@ -8,6 +8,9 @@ import numpy as np, torch
 import bench
 import sibrar_amd as S
 dev = 'cuda:0'
+if os.environ.get('SWEEP') is not None:      # lab: sweep period of the deferred table (0: no sweep)
+    from importlib import import_module
+    import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine').DeferredTable.SWEEP_EVERY = int(os.environ['SWEEP'])
 ds, net = bench.build(S, bench.C2, dev)
 for B, n in ((8192, 100), (256, 400), (8192, 100), (256, 400)):
     dt, _ = bench.bench_training(S, ds, net, dev, B, n, 5, 0, 1, time_kernels=False)
