@@ -73,6 +73,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef S5_RF
 #define S5_RF 32                         // tiles between two threshold refreshes in the steady state
 #endif
+#ifndef S5_LADDER
+#define S5_LADDER 0                      // lab: 1 = maximum + compare of a register pair in one asm block (no s_nop pads), 2 = and no OR
+                                         // over the pairs. Fewer instructions, not faster (in-process A/B: +1 %, +2 %): the consumer waves are
+                                         // not issue-bound in the ladder
+#endif
 
 // All 64 lanes: the scorer's OVERFLOW path (a (user, half) buffer ran full: ties at the threshold, or a threshold that cannot rise).
 // The k best of the n0 + n1 raw entries of a user's two buffer halves are found by a bitwise binary search for the k-th largest
@@ -640,11 +645,24 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) gm[nj * 8 + g] = __ballot(s5_max2(acc[nj][2 * g], acc[nj][2 * g + 1]) > thr);
+      for (int g = 0; g < 8; ++g) {
+#if S5_LADDER >= 1
+        // maximum and compare in ONE asm block: behind a separate v_max block hipcc pads every v_cmp with an s_nop (sixteen issue
+        // slots per tile that no hazard asks for)
+        float mx;
+        asm("v_max_f32 %1, %2, %3\n\tv_cmp_gt_f32_e64 %0, %1, %4" : "=s"(gm[nj * 8 + g]), "=&v"(mx) : "v"(acc[nj][2 * g]), "v"(acc[nj][2 * g + 1]), "v"(thr));
+#else
+        gm[nj * 8 + g] = __ballot(s5_max2(acc[nj][2 * g], acc[nj][2 * g + 1]) > thr);
+#endif
+      }
     }
+#if S5_LADDER >= 2
+    const bool any_g = true;                                 // the sixteen scalar tests below cost what their OR would
+#else
     unsigned long long any_g = 0ull;
 #pragma unroll
     for (int i = 0; i < 8 * NJ; ++i) any_g |= gm[i];
+#endif
     if constexpr (DBG == 2) { if (any_g) asm volatile("s_nop 0"); continue; }
     if (any_g) {
       // item of register r: nj * 32 + (r & 3) + 8 * (r >> 2) (+ 4 * half, in item_lane); exclusion bit nj * 16 + r. A pair that
