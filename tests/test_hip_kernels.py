@@ -410,6 +410,55 @@ def test_fused_f16_scorer_matches_unfused(Bu, I, D, k):
     assert not torch.isinf(got).any()
 
 
+@pytest.mark.parametrize('case', ['one_remainder_unit', 'seven_parts', 'two_parts', 'remainder_too_large', 'two_full_ragged',
+                                  'thirteen_full', 'several_rounds', 'one_remainder_unit_long_catalogue', 'one_remainder_unit_sorted'])
+def test_fused_f16_scorer_user_counts_around_the_wave_plan(case):
+    """The scorer's work plan (csrc/score_topk_f16_n.hip, s5_plan): W full waves per workgroup, and when the 32-user units do not
+    divide over the CUs, each remainder unit cut into P parts by item tile on one more wave of P workgroups, merged by the final
+    selection. User counts on every branch of that plan — P = 8 / 7 / 2, a remainder too large to cut, a ragged last unit, the
+    largest W with a part wave, more units than one round holds — with catalogues of fewer tiles than parts (parts without a tile),
+    a catalogue long enough for the prefix pass, and scores that increase with the item index (every part overflows), all with
+    exclusions: == fp64 matmul of the same fp16 inputs -> mask -> exact top-k."""
+    ops = S().ops
+    G = torch.cuda.get_device_properties(0).multi_processor_count
+    Wf, R, ragged, I, D, k = {'one_remainder_unit': (1, 1, 0, 300, 64, 10), 'seven_parts': (1, G // 7, 0, 300, 128, 10),
+                              'two_parts': (1, G // 2, 0, 300, 64, 10), 'remainder_too_large': (1, G // 2 + 1, 0, 300, 64, 10),
+                              'two_full_ragged': (2, 6, 7, 300, 128, 20), 'thirteen_full': (13, 3, 0, 200, 64, 5),
+                              'several_rounds': (14, 0, 5, 200, 64, 5), 'one_remainder_unit_long_catalogue': (1, 1, 0, 7000, 64, 20),
+                              'one_remainder_unit_sorted': (1, 1, 0, 2000, 64, 20)}[case]
+    Bu = 32 * (Wf * G + R) - (32 - ragged if ragged else 0) + (32 if ragged else 0)
+    g = torch.Generator().manual_seed(90)
+    u = (torch.randn(Bu, D, generator=g) / 4).half()
+    it = (torch.randn(I, D, generator=g) / 4).half()
+    if case.endswith('sorted'):
+        it = torch.zeros(I, D)
+        it[:, 0] = torch.linspace(-1, 1, I)
+        it = it.half()
+        u[:, 0] = u[:, 0].abs() + 0.5
+        u[:, 1:] = 0
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.integers(0, I, size=(Bu, 3)), axis=1).astype(np.int32)       # three excluded items per user (duplicates possible)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((np.ones(Bu * 3, dtype=np.int8), cols.reshape(-1), np.arange(0, 3 * Bu + 1, 3)), shape=(Bu, I))
+    m.sum_duplicates()
+    m.sort_indices()
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(DEV)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(DEV)
+    val, idx = ops.score_topk_f16(u.to(DEV), it.to(DEV), k, torch.arange(Bu, device=DEV), indptr, indices)
+    val, idx = val.cpu(), idx.cpu().long()
+    for lo in range(0, Bu, 16384):                                                # reference in slices: [Bu, I] doubles at once is 6 GB
+        hi = min(Bu, lo + 16384)
+        ref = u[lo:hi].double() @ it.double().t()
+        ref[torch.from_numpy(m[lo:hi].toarray() != 0)] = -float('inf')
+        tv, _ = torch.topk(ref, k, sorted=True)
+        close(val[lo:hi], tv, rtol=1e-5, atol=1e-5, what=f'values of users {lo}..{hi}')
+        got = torch.gather(ref, 1, idx[lo:hi])
+        close(got, tv, rtol=1e-5, atol=1e-5, what=f'indices of users {lo}..{hi}')
+        assert not torch.isinf(got).any()
+        srt = idx[lo:hi]
+        assert (torch.sort(srt, dim=1).values[:, 1:] != torch.sort(srt, dim=1).values[:, :-1]).all()      # distinct items per user
+
+
 def test_fused_f16_scorer_sorted_catalogue_and_item_offset():
     """Adversarial order: scores increase with the item index, so every tile overflows the candidate buffers."""
     ops = S().ops
