@@ -687,6 +687,7 @@ def bench_c3(S, device, steps):
                 roof['all_gemms'] = gemm_table(timings, n_steps)[:12]
                 gemm_ms = sum(r['ms_per_step'] for r in gemm_table(timings, n_steps))
                 roof['gemm_ms_per_step'] = round(gemm_ms, 4)
+                roof['all_kernels'] = kernel_table(timings, n_steps)[:24]
                 out['roofline'] = roof
     return out
 

@@ -201,6 +201,14 @@ int sbr_csr_project_fwd(const long* indptr, const int* indices, const float* val
                         void* stream);
 int sbr_csr_project_bwd(const long* indptr, const int* indices, const float* vals, const float* dZ, long ldz, const int* rows,
                         float* dWt, long ldw, long n, int C, void* stream);
+/* the same gradient in gather form (new in ABI 3): the slot gradients are added up per entity into the workspace dZe
+ * [n_entities, C] (overwritten; lde = C), and every feature column then sums the rows of the entities that have it — the forward
+ * kernel over the TRANSPOSED feature matrix (t_indptr / t_indices / t_vals: its CSR form, [n_cols, n_entities]), no atomics on
+ * dWt, fixed summation order. One float atomic per (slot, column) instead of one per (slot, nnz, column): Onion18 at batch 4096,
+ * 1.25 ms -> see DESIGN.md. Needs C % 4 == 0, C <= 1024. (algorithms/sgd_alg.py:1380, the backward of that Linear.) */
+int sbr_csr_project_bwd_gather(const long* t_indptr, const int* t_indices, const float* t_vals, const float* dZ, long ldz,
+                               const int* rows, long n, float* dZe, long lde, long n_entities, float* dWt, long ldw, long n_cols,
+                               int C, void* stream);
 
 /* dZ[j, :] = dY[ii(j), :] * act'(Y[ii(j), :]) — autograd of the activations of modules/polylinear.py:63-72 */
 int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz, long n, int C,

@@ -507,6 +507,9 @@ __global__ void csr_project_bwd_kernel(const long* __restrict__ indptr, const in
 // every G-th nnz (four nnz in flight per lane), groups are combined through LDS. Backward: the four waves take 64-nnz blocks
 // round robin; a block's column indices are loaded once (one per lane) and broadcast, and every nnz becomes one
 // 256-byte-contiguous float atomic per 64 columns (the full-rate form, MI355X_MICROARCH.md "float atomic add").
+// ACC (the backward pass in its gather form, sbr_csr_project_bwd_gather): the same sum over the TRANSPOSED matrix — row j = feature
+// column j, its entries the entities that have the feature, Wt = the per-entity gradient rows — added to out[j, :]; rows may be null.
+template <bool ACC>
 __global__ __launch_bounds__(256) void csr_project_fwd_wg_kernel(
     const long* __restrict__ indptr, const int* __restrict__ indices, const float* __restrict__ vals,
     const float* __restrict__ Wt, long ldw, const float* __restrict__ bias, const int* __restrict__ rows,
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void csr_project_fwd_wg_kernel(
   const int LPG = C >> 2;                 // lanes per nnz group
   const int G = 256 / LPG;                // nnz groups (>= 1: C <= 1024)
   const int g = t / LPG, l = t - g * LPG;
-  const long r = rows[j];
+  const long r = rows ? (long)rows[j] : j;
   const long beg = indptr[r], end = indptr[r + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g < G) {
@@ -549,8 +552,16 @@ __global__ __launch_bounds__(256) void csr_project_fwd_wg_kernel(
       const float4 p = part[k * LPG + t];
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    if (bias) { s.x += bias[4 * t]; s.y += bias[4 * t + 1]; s.z += bias[4 * t + 2]; s.w += bias[4 * t + 3]; }
     float* o = out + (out_idx ? (long)out_idx[j] : j) * ldo + 4 * t;
+    if constexpr (ACC) {
+      if (beg < end) {
+        float4 cur = *reinterpret_cast<float4*>(o);
+        cur.x += s.x; cur.y += s.y; cur.z += s.z; cur.w += s.w;
+        *reinterpret_cast<float4*>(o) = cur;
+      }
+      return;
+    }
+    if (bias) { s.x += bias[4 * t]; s.y += bias[4 * t + 1]; s.z += bias[4 * t + 2]; s.w += bias[4 * t + 3]; }
     o[0] = sbr_act(s.x, act); o[1] = sbr_act(s.y, act); o[2] = sbr_act(s.z, act); o[3] = sbr_act(s.w, act);
   }
 }
@@ -586,7 +597,7 @@ extern "C" int sbr_csr_project_fwd(const long* indptr, const int* indices, const
   if (n == 0) return SBR_OK;
   SBR_REQUIRE(indptr && indices && Wt && rows && out, "sbr_csr_project_fwd: null operand");
   if ((C & 3) == 0 && C <= 1024 && (ldw & 3) == 0 && (((uintptr_t)Wt) & 15) == 0) {
-    csr_project_fwd_wg_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out, ldo,
+    csr_project_fwd_wg_kernel<false><<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out, ldo,
                                                                            out_idx, C, act);
   } else {
     csr_project_fwd_kernel<<<sbr_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(indptr, indices, vals, Wt, ldw, bias, rows, out,
@@ -612,6 +623,37 @@ extern "C" int sbr_csr_project_bwd(const long* indptr, const int* indices, const
       csr_project_bwd_kernel<<<sbr_cdiv(n, 4), 256, 0, s>>>(indptr, indices, vals, dZ, ldz, rows, dWt, ldw, n, C);
   }
   SBR_CHECK_LAUNCH("sbr_csr_project_bwd");
+  return SBR_OK;
+}
+
+__global__ void rowops_zero_kernel(float4* __restrict__ p, long n4) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The same gradient in GATHER form: dWt = X^T dZ with X the [slots, n_cols] matrix of the slots' feature rows. The scatter form
+// above issues one float atomic per (slot, nnz, column) — Onion18 at batch 4096: 30,805 slots x ~24 nnz x 512 columns = 0.38 G
+// atomics, 1.25 ms, the largest kernel of that step. Here the slot gradients are first added up per ENTITY (dZe[rows[j], :] +=
+// dZ[j, :]: one atomic per slot and column), and every feature column then sums the rows of the entities that have it — the
+// forward kernel run over the transposed matrix, no atomics, one writer per row of dWt, a fixed summation order. Entities outside
+// the batch contribute zero rows (read, not skipped: at these batch sizes nearly every entity is in the batch).
+// (t_indptr, t_indices, t_vals): the CSR form of the TRANSPOSED feature matrix [n_cols, n_entities]; dZe: workspace
+// [n_entities, C] (ldz_e floats per row), overwritten.
+extern "C" int sbr_csr_project_bwd_gather(const long* t_indptr, const int* t_indices, const float* t_vals, const float* dZ, long ldz,
+                                          const int* rows, long n, float* dZe, long lde, long n_entities, float* dWt, long ldw,
+                                          long n_cols, int C, void* stream) {
+  if (n == 0 || n_cols == 0) return SBR_OK;
+  SBR_REQUIRE(t_indptr && t_indices && dZ && rows && dZe && dWt, "sbr_csr_project_bwd_gather: null operand");
+  SBR_REQUIRE((C & 3) == 0 && C >= 4 && C <= 1024 && lde == C && (ldw & 3) == 0 && (((uintptr_t)dZe | (uintptr_t)dWt) & 15) == 0 && n_entities >= 1,
+              "sbr_csr_project_bwd_gather: needs C %% 4 == 0, C <= 1024, a dense 16-byte aligned workspace (lde = C) and 16-byte aligned gradient rows");
+  hipStream_t s = (hipStream_t)stream;
+  const long n4 = n_entities * C / 4;
+  int zb = (int)sbr_cdiv(n4, 256);
+  rowops_zero_kernel<<<zb > 4096 ? 4096 : zb, 256, 0, s>>>((float4*)dZe, n4);
+  SBR_CHECK_LAUNCH("sbr_csr_project_bwd_gather (zero)");
+  const int rc = sbr_scatter_add_rows(dZ, ldz, nullptr, rows, dZe, lde, n, C, stream);
+  if (rc) return rc;
+  csr_project_fwd_wg_kernel<true><<<(unsigned)n_cols, 256, 0, s>>>(t_indptr, t_indices, t_vals, dZe, lde, nullptr, nullptr, dWt, ldw, nullptr, C, 0);
+  SBR_CHECK_LAUNCH("sbr_csr_project_bwd_gather");
   return SBR_OK;
 }
 

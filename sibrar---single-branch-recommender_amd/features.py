@@ -159,3 +159,18 @@ class DeviceTable(nn.Module):
             self.register_buffer('tags', torch.from_numpy(np.ascontiguousarray(tags)), persistent=False)
         self.register_buffer('rowmap', None if rowmap is None else torch.from_numpy(np.ascontiguousarray(rowmap)),
                              persistent=False)
+        self._transposed = None
+
+    def transposed(self):
+        """CSR form of the TRANSPOSED matrix of a 'csr' feature, on its device: (indptr int64 [dim + 1], indices int32 [nnz] = entity
+        rows, data float32 [nnz] or None). Built once, on first use (the gather form of the projector's backward pass)."""
+        if self._transposed is None or self._transposed[0].device != self.indptr.device:
+            counts = torch.bincount(self.indices.long(), minlength=self.dim)
+            t_indptr = torch.zeros(self.dim + 1, dtype=torch.int64, device=self.indptr.device)
+            t_indptr[1:] = torch.cumsum(counts, 0)
+            row_of = torch.repeat_interleave(torch.arange(self.n_rows, device=self.indptr.device), self.indptr[1:] - self.indptr[:-1])
+            order = torch.sort(self.indices.long(), stable=True).indices          # by column, entity rows ascending within one
+            t_indices = row_of[order].to(torch.int32).contiguous()
+            t_data = None if self.data is None else self.data[order].contiguous()
+            self._transposed = (t_indptr, t_indices, t_data)
+        return self._transposed

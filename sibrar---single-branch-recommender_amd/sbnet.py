@@ -186,6 +186,13 @@ class FeatureEmbedding(nn.Module):
     """algorithms/sgd_alg.py:1279-1396: per-feature front end. dense / CSR features -> PolyLinear projector (activation on
     the output too), categorical -> nn.Embedding, tag -> nn.EmbeddingBag(mean, padding)."""
 
+    # CSR modality, backward pass of the projector: gather form (sbr_csr_project_bwd_gather) when the step has at least n_entities /
+    # CSR_GATHER_MIN_FRACTION slots of the modality (fewer: the scatter form's atomics are cheaper than reading every nnz) and the
+    # per-entity workspace stays below CSR_GATHER_MAX_WS floats
+    CSR_GATHER_MIN_FRACTION = 8
+    CSR_GATHER_MAX_WS = 1 << 28
+
+
     def __init__(self, feature, embedding_dim: int = None, pre_embedding_layers: List[int] = None,
                  post_embedding_layers: List[int] = None, activation_fn='relu'):
         super().__init__()
@@ -237,6 +244,7 @@ class FeatureEmbedding(nn.Module):
             lin.weight = nn.Parameter(w.t().contiguous().t())
         self._act = ops.act_code(activation_fn)
         self._colsum_ws = {}            # layer -> column-reduction workspace of its folded bias gradient (fused step)
+        self._csr_ws = None             # [n_entities, C] per-entity gradient rows of a CSR modality (gather form of its backward)
 
     # -- front-end protocol used by FrontEndFn ---------------------------------------------------------------------------
     @property
@@ -346,8 +354,22 @@ class FeatureEmbedding(nn.Module):
                     assert dWt.is_contiguous()
                 else:
                     dWt = torch.zeros(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
-                call('sbr_csr_project_bwd', ptr(t.indptr), ptr(t.indices), ptr(t.data), ptr(dz), dz.stride(0), ptr(rows),
-                     ptr(dWt), dWt.stride(0), n, W.shape[0], st)
+                C = W.shape[0]
+                if (n * self.CSR_GATHER_MIN_FRACTION >= t.n_rows and C % 4 == 0 and C <= 1024 and dWt.stride(0) % 4 == 0
+                        and dWt.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS):
+                    # many slots: add the slot gradients up per entity first, then every feature column gathers the rows of the
+                    # entities that have it (the forward kernel over the transposed matrix; no atomics on the weight gradient)
+                    ti, tj, tv = t.transposed()
+                    ws = self._csr_ws
+                    if ws is None or ws.shape != (t.n_rows, C) or ws.device != dz.device:
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError('the CSR gradient workspace must exist before a step is captured (run one plain step first)')
+                        ws = self._csr_ws = torch.empty(t.n_rows, C, device=dz.device, dtype=torch.float32)
+                    call('sbr_csr_project_bwd_gather', ptr(ti), ptr(tj), ptr(tv), ptr(dz), dz.stride(0), ptr(rows), n, ptr(ws), C, t.n_rows,
+                         ptr(dWt), dWt.stride(0), W.shape[1], C, st)
+                else:
+                    call('sbr_csr_project_bwd', ptr(t.indptr), ptr(t.indices), ptr(t.data), ptr(dz), dz.stride(0), ptr(rows),
+                         ptr(dWt), dWt.stride(0), n, C, st)
                 grads[0] = dWt.t()
             elif l == 0:
                 if tn is not None and go[0] is not None:

@@ -632,6 +632,18 @@ def test_csr_projector_long_tailed_rows(C, act):
              n, C, ops.stream())
         ref_dw = dz.t() @ d[rows.long()]                  # [C, n_cols]
         close(dwt.cpu().t(), ref_dw, rtol=1e-4, atol=1e-5, what=f'csr dW vals={use_vals}', norm_rtol=1e-5)
+        if C % 4 == 0:
+            # the gather form: slot gradients summed per entity, then every feature column gathers its entities' rows over the
+            # TRANSPOSED matrix (features.DeviceTable.transposed builds the same arrays on the device); accumulates into dWt
+            mt = sp.csr_matrix((vals if use_vals else np.ones_like(vals), indices, indptr), shape=(n_rows, n_cols)).T.tocsr()
+            mt.sort_indices()
+            tp, tx = torch.from_numpy(mt.indptr.astype(np.int64)).to(DEV), torch.from_numpy(mt.indices.astype(np.int32)).to(DEV)
+            tv = torch.from_numpy(mt.data.astype(np.float32)).to(DEV) if use_vals else None
+            ws = torch.full((n_rows, C), float('nan'), device=DEV)            # overwritten by the call
+            dwt2 = torch.full_like(wt, 0.25)
+            call('sbr_csr_project_bwd_gather', ptr(tp), ptr(tx), ptr(tv), ptr(dz_d), C, ptr(rows_d), n, ptr(ws), C, n_rows, ptr(dwt2),
+                 dwt2.stride(0), n_cols, C, ops.stream())
+            close(dwt2.cpu().t() - 0.25, ref_dw, rtol=1e-4, atol=1e-5, what=f'csr dW (gather form) vals={use_vals}', norm_rtol=1e-5)
 
 
 @pytest.mark.parametrize('R,n_mod,pad', [(1, 1, 0), (24, 2, 64), (4096, 3, 0), (4097, 2, 128), (90112, 2, 1024), (180224, 8, 0)])
