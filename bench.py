@@ -213,7 +213,7 @@ def gemm_kernel(mode, M, N, K, gathered):
             return (f'void gemm_split_kernel<{mode}, ', 'bf16-split shared-MLP kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
         if mode == 0 and lib.sbr_gemm_split_proj_supported(int(M), int(N), int(K)):
             return ('gemm_split_proj_kernel', 'bf16-split projector kernel (csrc/gemm_split_f32.hip)', 6, 'bf16')
-        if lib.sbr_gemm_split_wide_supported(int(M), int(N), int(K)):
+        if lib.sbr_gemm_split_wide_supported(int(M), int(N), int(K)) and ops.wide_pays(int(M), int(N), int(K)):
             return ('gemm_split_wide_kernel', 'wide bf16-split kernel (csrc/gemm_split_wide_f32.hip)', 6, 'bf16')
     return ('void gemm_ring_kernel<', 'fp32 MFMA ring kernel (csrc/gemm_ring_f32.hip)', 1, 'f32')
 

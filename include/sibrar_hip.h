@@ -207,8 +207,10 @@ int sbr_csr_project_bwd(const long* indptr, const int* indices, const float* val
  * dWt, fixed summation order. One float atomic per (slot, column) instead of one per (slot, nnz, column): Onion18 at batch 4096,
  * 1.25 ms -> see DESIGN.md. Needs C % 4 == 0, C <= 1024. (algorithms/sgd_alg.py:1380, the backward of that Linear.) */
 int sbr_csr_project_bwd_gather(const long* t_indptr, const int* t_indices, const float* t_vals, const float* dZ, long ldz,
-                               const int* rows, long n, float* dZe, long lde, long n_entities, float* dWt, long ldw, long n_cols,
-                               int C, void* stream);
+                               const int* dz_idx, const int* rows, long n, float* dZe, long lde, long n_entities, float* dWt,
+                               long ldw, long n_cols, int C, void* stream);
+/* dz_idx (may be NULL): slot j's gradient row is dZ[dz_idx[j], :]. sbr_bag_mean_bwd in gather form is this entry point with the
+ * transpose of X[entity, tag] = 1 / (number of tags of the entity). */
 
 /* dZ[j, :] = dY[ii(j), :] * act'(Y[ii(j), :]) — autograd of the activations of modules/polylinear.py:63-72 */
 int sbr_act_grad_gather(const float* dY, const float* Y, long ld, const int* in_idx, float* dZ, long ldz, long n, int C,

@@ -638,9 +638,11 @@ __global__ void rowops_zero_kernel(float4* __restrict__ p, long n4) {
 // the batch contribute zero rows (read, not skipped: at these batch sizes nearly every entity is in the batch).
 // (t_indptr, t_indices, t_vals): the CSR form of the TRANSPOSED feature matrix [n_cols, n_entities]; dZe: workspace
 // [n_entities, C] (ldz_e floats per row), overwritten.
+// dz_idx (may be null): slot j's gradient row is dZ[dz_idx[j], :]. An EmbeddingBag(mean) over padded tag lists is the same product
+// with X[entity, tag] = 1 / (tags of the entity): sbr_bag_mean_bwd in gather form is this entry point over that matrix's transpose.
 extern "C" int sbr_csr_project_bwd_gather(const long* t_indptr, const int* t_indices, const float* t_vals, const float* dZ, long ldz,
-                                          const int* rows, long n, float* dZe, long lde, long n_entities, float* dWt, long ldw,
-                                          long n_cols, int C, void* stream) {
+                                          const int* dz_idx, const int* rows, long n, float* dZe, long lde, long n_entities,
+                                          float* dWt, long ldw, long n_cols, int C, void* stream) {
   if (n == 0 || n_cols == 0) return SBR_OK;
   SBR_REQUIRE(t_indptr && t_indices && dZ && rows && dZe && dWt, "sbr_csr_project_bwd_gather: null operand");
   SBR_REQUIRE((C & 3) == 0 && C >= 4 && C <= 1024 && lde == C && (ldw & 3) == 0 && (((uintptr_t)dZe | (uintptr_t)dWt) & 15) == 0 && n_entities >= 1,
@@ -650,7 +652,7 @@ extern "C" int sbr_csr_project_bwd_gather(const long* t_indptr, const int* t_ind
   int zb = (int)sbr_cdiv(n4, 256);
   rowops_zero_kernel<<<zb > 4096 ? 4096 : zb, 256, 0, s>>>((float4*)dZe, n4);
   SBR_CHECK_LAUNCH("sbr_csr_project_bwd_gather (zero)");
-  const int rc = sbr_scatter_add_rows(dZ, ldz, nullptr, rows, dZe, lde, n, C, stream);
+  const int rc = sbr_scatter_add_rows(dZ, ldz, dz_idx, rows, dZe, lde, n, C, stream);
   if (rc) return rc;
   csr_project_fwd_wg_kernel<true><<<(unsigned)n_cols, 256, 0, s>>>(t_indptr, t_indices, t_vals, dZe, lde, nullptr, nullptr, dWt, ldw, nullptr, C, 0);
   SBR_CHECK_LAUNCH("sbr_csr_project_bwd_gather");

@@ -161,9 +161,23 @@ class DeviceTable(nn.Module):
                              persistent=False)
         self._transposed = None
 
-    def transposed(self):
+    def transposed(self, n_cols=None):
         """CSR form of the TRANSPOSED matrix of a 'csr' feature, on its device: (indptr int64 [dim + 1], indices int32 [nnz] = entity
-        rows, data float32 [nnz] or None). Built once, on first use (the gather form of the projector's backward pass)."""
+        rows, data float32 [nnz] or None). Built once, on first use (the gather form of the projector's backward pass).
+        A 'tag' feature: the transpose of X[entity, tag] = 1 / (tags of the entity) — the matrix an EmbeddingBag(mean) multiplies by —
+        with ``n_cols`` rows (the bag's weight rows, padding row included: it has no entries)."""
+        if self.kind == 'tag':
+            if self._transposed is None or self._transposed[0].device != self.tags.device or self._transposed[0].numel() != n_cols + 1:
+                real = self.tags != self.pad                                                  # [n_rows, T]
+                cnt = real.sum(1)
+                ent = torch.arange(self.n_rows, device=self.tags.device)[:, None].expand_as(self.tags)[real]
+                tag = self.tags[real].long()
+                val = (1.0 / cnt.float())[ent]
+                order = torch.sort(tag, stable=True).indices
+                t_indptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=self.tags.device)
+                t_indptr[1:] = torch.cumsum(torch.bincount(tag, minlength=n_cols), 0)
+                self._transposed = (t_indptr, ent[order].to(torch.int32).contiguous(), val[order].contiguous())
+            return self._transposed
         if self._transposed is None or self._transposed[0].device != self.indptr.device:
             counts = torch.bincount(self.indices.long(), minlength=self.dim)
             t_indptr = torch.zeros(self.dim + 1, dtype=torch.int64, device=self.indptr.device)

@@ -120,14 +120,19 @@ def _wres_ok(M, N, K, *tensors) -> bool:
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 for t in tensors)
 
 
+def wide_pays(M, N, K) -> bool:
+    """Shapes at which the wide bf16-split kernel is used when it could be (measured against the fp32 ring kernel,
+    tools/lab/wide_time.py): enough 256 x 256 tiles to fill the chip's 256 workgroup slots, and a wide or deep product (256 x 256
+    layers run as fast on the fp32 pipe). bench.py prices a GEMM signature with the same rule."""
+    return not _WIDE_HEURISTIC or (-(-M // 256) * (N // 256) >= 176 and max(N, K) >= 512)
+
+
 def _wide_ok(M, N, K, a, w, out, nt: bool) -> bool:
     """The wide bf16-split kernel (csrc/gemm_split_wide_f32.hip) takes the product: enough rows, N = 256 i, K = 32 j >= 64, 16-byte
     aligned rows of A (and of W for NT), unit column strides."""
     if not _SPLIT or M < _SPLIT_MIN_ROWS or not lib().sbr_gemm_split_wide_supported(int(M), int(N), int(K)):
         return False
-    # where it pays (measured against the fp32 ring kernel, tools/lab/wide_time.py): enough 256 x 256 tiles to fill the chip's 256
-    # workgroup slots, and a wide or deep product (256 x 256 layers run as fast on the fp32 pipe)
-    if _WIDE_HEURISTIC and (-(-M // 256) * (N // 256) < 176 or max(N, K) < 512):
+    if not wide_pays(M, N, K):
         return False
     ok = a.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
     return ok and (not nt or (w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0))

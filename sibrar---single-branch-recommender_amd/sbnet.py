@@ -322,8 +322,22 @@ class FeatureEmbedding(nn.Module):
             return [dW]
         if self.kind == 'tag':
             dW = torch.zeros_like(p[0]) if grad_out is None else grad_out[0]
+            C = dout.shape[1]
+            if (n * self.CSR_GATHER_MIN_FRACTION >= t.n_rows and C % 4 == 0 and C <= 1024 and dW.stride(0) % 4 == 0
+                    and dW.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS):
+                # the mean over a tag list is a product with X[entity, tag] = 1 / (tags of the entity): the gather form of the CSR
+                # projector's backward pass (per-entity sums, then every tag gathers its entities' rows) serves it as it is
+                ti, tj, tv = t.transposed(dW.shape[0])
+                ws = self._csr_ws
+                if ws is None or ws.shape != (t.n_rows, C) or ws.device != dout.device:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError('the tag gradient workspace must exist before a step is captured (run one plain step first)')
+                    ws = self._csr_ws = torch.empty(t.n_rows, C, device=dout.device, dtype=torch.float32)
+                call('sbr_csr_project_bwd_gather', ptr(ti), ptr(tj), ptr(tv), ptr(dout), dout.stride(0), ptr(slots), ptr(rows), n, ptr(ws), C,
+                     t.n_rows, ptr(dW), dW.stride(0), dW.shape[0], C, st)
+                return [dW]
             call('sbr_bag_mean_bwd', ptr(dout), dout.stride(0), ptr(slots), ptr(t.tags), t.T, t.pad, ptr(rows), ptr(dW),
-                 dW.stride(0), n, dout.shape[1], st)
+                 dW.stride(0), n, C, st)
             return [dW]
         L = len(p) // 2
         grads = [None] * (2 * L)
@@ -365,7 +379,7 @@ class FeatureEmbedding(nn.Module):
                         if torch.cuda.is_current_stream_capturing():
                             raise RuntimeError('the CSR gradient workspace must exist before a step is captured (run one plain step first)')
                         ws = self._csr_ws = torch.empty(t.n_rows, C, device=dz.device, dtype=torch.float32)
-                    call('sbr_csr_project_bwd_gather', ptr(ti), ptr(tj), ptr(tv), ptr(dz), dz.stride(0), ptr(rows), n, ptr(ws), C, t.n_rows,
+                    call('sbr_csr_project_bwd_gather', ptr(ti), ptr(tj), ptr(tv), ptr(dz), dz.stride(0), None, ptr(rows), n, ptr(ws), C, t.n_rows,
                          ptr(dWt), dWt.stride(0), W.shape[1], C, st)
                 else:
                     call('sbr_csr_project_bwd', ptr(t.indptr), ptr(t.indices), ptr(t.data), ptr(dz), dz.stride(0), ptr(rows),

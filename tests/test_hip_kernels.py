@@ -641,9 +641,62 @@ def test_csr_projector_long_tailed_rows(C, act):
             tv = torch.from_numpy(mt.data.astype(np.float32)).to(DEV) if use_vals else None
             ws = torch.full((n_rows, C), float('nan'), device=DEV)            # overwritten by the call
             dwt2 = torch.full_like(wt, 0.25)
-            call('sbr_csr_project_bwd_gather', ptr(tp), ptr(tx), ptr(tv), ptr(dz_d), C, ptr(rows_d), n, ptr(ws), C, n_rows, ptr(dwt2),
+            call('sbr_csr_project_bwd_gather', ptr(tp), ptr(tx), ptr(tv), ptr(dz_d), C, None, ptr(rows_d), n, ptr(ws), C, n_rows, ptr(dwt2),
                  dwt2.stride(0), n_cols, C, ops.stream())
             close(dwt2.cpu().t() - 0.25, ref_dw, rtol=1e-4, atol=1e-5, what=f'csr dW (gather form) vals={use_vals}', norm_rtol=1e-5)
+
+
+@pytest.mark.parametrize('kind', ['tag', 'csr'])
+def test_front_backward_of_sparse_modalities_gather_form_equals_scatter_form(kind):
+    """FeatureEmbedding.front_backward of a tag bag (nn.EmbeddingBag(mean, padding), sgd_alg.py:1336-1337) and of a CSR projector
+    (sgd_alg.py:1380): with many slots the weight gradient is computed in gather form (per-entity sums, then every tag / feature
+    column gathers its entities' rows: features.DeviceTable.transposed + sbr_csr_project_bwd_gather), with few in scatter form
+    (one atomic per slot, entry and column). Both against the dense fp64 product, on the same slots: duplicated entities,
+    entities without any tag / entry, a tag used by every entity."""
+    import sibrar_amd as S
+    from importlib import import_module
+    pkg = S.ops.__name__.rsplit('.', 1)[0]
+    features, sbnet = import_module(pkg + '.features'), import_module(pkg + '.sbnet')
+    rng = np.random.default_rng(12)
+    n_ent, n_cols, C, T = 500, 37, 64, 6
+    if kind == 'tag':
+        tags = np.full((n_ent, T), n_cols, dtype=np.int64)                          # padding value = number of tags
+        for e in range(n_ent):
+            k_ = int(rng.integers(0, T + 1)) if e % 50 else 0                       # some entities have no tag at all
+            tags[e, :k_] = rng.choice(n_cols, size=k_, replace=False)
+            if k_ and e % 3 == 0:
+                tags[e, 0] = 5                                                      # a very common tag
+        feat = features.HostFeature('genres', 'tag', tags, n_categories=n_cols)
+        dense = np.zeros((n_ent, n_cols + 1))
+        for e in range(n_ent):
+            real = tags[e][tags[e] != n_cols]
+            for g_ in real:
+                dense[e, g_] += 1.0 / len(real)
+    else:
+        import scipy.sparse as sp
+        m = sp.random(n_ent, n_cols, density=0.15, format='csr', random_state=3, dtype=np.float32)
+        m.data[:] = 1.0
+        feat = features.HostFeature('interactions', 'csr', m)
+        dense = m.toarray().astype(np.float64)
+    torch.manual_seed(0)
+    fe = sbnet.FeatureEmbedding(feat, embedding_dim=C).to(DEV)
+    p = fe.front_params()
+    n = 3000
+    rows = torch.from_numpy(rng.integers(0, n_ent, size=n).astype(np.int32)).to(DEV)
+    slots = torch.from_numpy(rng.permutation(n + 50)[:n].astype(np.int32)).to(DEV)          # slot rows of the [R, C] matrix
+    dout = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(1)).to(DEV)
+    out = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(2)).abs().to(DEV) + 0.1  # positive: ReLU' = 1 everywhere
+    got = {}
+    for form, frac in (('gather', 1 << 30), ('scatter', 0)):
+        fe.CSR_GATHER_MIN_FRACTION = frac
+        hidden = [] if kind == 'tag' else [out]
+        grads = fe.front_backward(p, hidden, rows, n, out, dout, slots)
+        got[form] = grads[0].detach().double().cpu()
+    ref_in = dout.double().cpu()[slots.cpu().long()]                                 # [n, C]
+    X = torch.from_numpy(dense)[rows.cpu().long()]                                   # [n, n_cols (+ pad)]
+    ref = X.t() @ ref_in if kind == 'tag' else ref_in.t() @ X                         # bag weight [n_cols + 1, C] / Linear weight [C, n_cols]
+    for form in ('gather', 'scatter'):
+        close(got[form], ref, rtol=1e-4, atol=1e-5, what=f'{kind} weight gradient, {form} form', norm_rtol=1e-5)
 
 
 @pytest.mark.parametrize('R,n_mod,pad', [(1, 1, 0), (24, 2, 64), (4096, 3, 0), (4097, 2, 128), (90112, 2, 1024), (180224, 8, 0)])
