@@ -294,8 +294,32 @@ def test_fused_scorer_loss_statistics_kernel(kind, B, N, D):
     assert seen[0][0] == seen[1][0]
 
 
+def test_infonce_small_groups_read_in_place_from_the_slot_tensor():
+    """The training step's call (engine: the two modality slices e[:, 0, :] / e[:, 1, :] of the [S, 2, D] embedding tensor read in
+    place, ld = 2 D; gradients written into a [S, 2, D] tensor the same way) on the one-wave-per-group kernel: Onion18's group shape
+    (N = 11, D = 128) with a group count that is no multiple of the four groups of a workgroup."""
+    import sibrar_amd as Sm
+    from oracle import model_ref
+    ops = Sm.ops
+    G, N, D = 1027, 11, 128
+    e = _rand(G * N, 2, D, seed=52) * 0.5
+    ar, br = e[:, 0, :].reshape(G, N, D).clone().requires_grad_(True), e[:, 1, :].reshape(G, N, D).clone().requires_grad_(True)
+    ref = model_ref.info_nce(ar, br, 0.3)
+    ref.backward()
+    ed = e.to(DEV)
+    loss = torch.zeros((), device=DEV, dtype=torch.float64)
+    scale = 1.0 / (G * N)
+    ops.infonce_fwd(ed.data_ptr(), ed.data_ptr() + 4 * D, 2 * D, G, N, D, 0.3, scale, loss, DEV)
+    close(loss.cpu(), ref.detach().double(), rtol=1e-5, atol=1e-7, what='loss')
+    de = torch.full_like(ed, float('nan'))
+    gout = torch.ones((), device=DEV)
+    ops.infonce_bwd(ed.data_ptr(), ed.data_ptr() + 4 * D, 2 * D, G, N, D, 0.3, scale, gout, de.data_ptr(), de.data_ptr() + 4 * D, 2 * D, DEV)
+    close(de[:, 0, :].cpu().reshape(G, N, D), ar.grad, rtol=2e-4, atol=1e-7, what='da', norm_rtol=1e-4)
+    close(de[:, 1, :].cpu().reshape(G, N, D), br.grad, rtol=2e-4, atol=1e-7, what='db', norm_rtol=1e-4)
+
+
 @pytest.mark.parametrize('G,N,D', [(1, 2, 3), (7, 11, 16), (3, 101, 64), (1, 176, 8), (64, 40, 16), (1, 256, 64), (2, 300, 30),
-                                   (1, 1000, 128)])
+                                   (1, 1000, 128), (4096, 11, 128), (5, 16, 256), (9, 1, 4), (130, 3, 64), (6, 17, 128)])
 def test_infonce_vs_oracle(G, N, D):
     import sibrar_amd as Sm
     from oracle import model_ref
