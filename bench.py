@@ -355,13 +355,15 @@ def step_roofline(timings, steps, batch, n_params, deferred_table=0, table_dim=0
             # dense AdamW (train/trainer.py:62-68 -> optimizer.step(), zero_grad()): reads p, g, m, v and writes p, m, v = 28 bytes per
             # parameter (the gradient reset only writes elements that are not +0 already). With the lookup user table updated row by
             # row (sbr_adam_step_rows) only the rows of the batch are touched: 28 bytes per element of at most `batch` rows.
-            byts = 28.0 * n_params if name != 'sbr_adam_step_rows' else 28.0 * (n_params - deferred_table + min(batch * table_dim, deferred_table))
+            # (+ the launch's sweep: 1/16 of the table's rows per step read and written without a gradient, 24 bytes per element)
+            byts = 28.0 * n_params if name != 'sbr_adam_step_rows' else (28.0 * (n_params - deferred_table + min(batch * table_dim, deferred_table))
+                                                                          + 24.0 * deferred_table / 16)
             t = top['avg_launch_ms'] * 1e-3
             traffic, note = pmc_symbol_traffic(ENTRY_KERNEL.get(name), batch)
             out = {'bound': 'hbm', 'achieved': round(byts / t / 1e9, 1), 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': round(byts / t / 1e9 / PEAK_HBM, 4),
                    'traffic': traffic, 'traffic_source': note, 'algorithmic_bytes': byts,
                    'kernel': f'{ENTRY_KERNEL.get(name)} ({name}): AdamW step + gradient reset + loss read-out over {n_params} parameters' +
-                             (f' ({deferred_table} of them a lookup table updated row by row: only the batch\'s rows are touched)' if name == 'sbr_adam_step_rows' else '') +
+                             (f' ({deferred_table} of them a lookup table updated row by row: the batch\'s rows + a 1/16 sweep per step)' if name == 'sbr_adam_step_rows' else '') +
                              ', 28 bytes per touched parameter', 'avg_launch_ms': top['avg_launch_ms'], 'kernel_ms_per_step': top['ms_per_step'],
                    'timing': TIMING_NOTE}
     if out is None:
