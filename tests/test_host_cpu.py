@@ -527,3 +527,49 @@ def test_device_containers_built_from_reference_objects_equal_the_product_loader
             assert np.array_equal(np.asarray(ds.items_in_split), z[p + '/items_in_split'])
             assert np.array_equal(np.asarray(ds.users_in_split), z[p + '/users_in_split'])
     assert n_tables == 24
+
+
+@pytest.mark.parametrize('kind', ['csr', 'tag'])
+def test_transposed_feature_tables_equal_the_scipy_transpose(kind):
+    """features.DeviceTable.transposed — the operand of the gather-form weight gradient of the CSR projector and of the tag bag
+    (sbr_csr_project_bwd_gather): the CSR arrays of X^T for the 'interactions' matrix (data/Feature.py:149-150), and of the transpose
+    of X[entity, tag] = 1 / (tags of the entity) for a padded tag list (nn.EmbeddingBag(mean, padding), sgd_alg.py:1336-1337), built
+    with torch ops only (so on the table's device) == scipy's transpose: indptr, entity rows ascending within a column, values;
+    weighted and all-ones matrices, empty rows and columns, an entity without tags, a duplicated tag."""
+    import scipy.sparse as sp
+    from importlib import import_module
+    features = import_module('sibrar---single-branch-recommender_amd.features')
+    rng = np.random.default_rng(3)
+    n_ent, n_cols = 60, 23
+    if kind == 'csr':
+        for weighted in (False, True):
+            m = sp.random(n_ent, n_cols, density=0.2, format='csr', random_state=4, dtype=np.float32)
+            m.data[:] = rng.standard_normal(m.nnz).astype(np.float32) if weighted else 1.0
+            m = m.tolil(); m[7, :] = 0; m[:, 5] = 0; m = m.tocsr(); m.eliminate_zeros()
+            t = features.DeviceTable(features.HostFeature('interactions', 'csr', m))
+            ip, ix, dv = t.transposed()
+            ref = m.T.tocsr(); ref.sort_indices()
+            assert np.array_equal(ip.numpy(), ref.indptr) and np.array_equal(ix.numpy(), ref.indices)
+            assert (dv is None) == (not weighted)
+            if weighted:
+                assert np.array_equal(dv.numpy(), ref.data)
+            assert t.transposed()[0] is ip                                     # built once
+    else:
+        T = 5
+        tags = np.full((n_ent, T), n_cols, dtype=np.int64)
+        for e in range(n_ent):
+            k_ = int(rng.integers(0, T + 1)) if e != 9 else 0
+            tags[e, :k_] = rng.choice(n_cols, size=k_, replace=False)
+        tags[3, :3] = [4, 4, 6]                                                # a duplicated tag counts twice, as in the bag's mean
+        t = features.DeviceTable(features.HostFeature('genres', 'tag', tags, n_categories=n_cols))
+        ip, ix, dv = t.transposed(n_cols + 1)
+        dense = np.zeros((n_ent, n_cols + 1), dtype=np.float64)
+        for e in range(n_ent):
+            real = tags[e][tags[e] != n_cols]
+            for g_ in real:
+                dense[e, g_] += 1.0 / len(real)
+        got = sp.csr_matrix((dv.numpy().astype(np.float64), ix.numpy(), ip.numpy()), shape=(n_cols + 1, n_ent)).toarray()
+        assert np.allclose(got, dense.T, rtol=1e-6, atol=0) and ip.numel() == n_cols + 2 and int(ip[-1]) == int((tags != n_cols).sum())
+        for c in range(n_cols + 1):                                            # entity rows ascending within a tag
+            seg = ix.numpy()[int(ip[c]):int(ip[c + 1])]
+            assert np.all(np.diff(seg) >= 0)
