@@ -73,6 +73,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef S5_RF
 #define S5_RF 32                         // tiles between two threshold refreshes in the steady state
 #endif
+#ifndef S5_SHAPE16
+#define S5_SHAPE16 0                     // lab (timing only, wrong results): every 32x32x16 MFMA as two 16x16x32 MFMAs — does the other shape
+                                         // hold a higher clock under the power limit in THIS kernel?
+#endif
 #ifndef S5_LADDER
 #define S5_LADDER 0                      // lab: 1 = maximum + compare of a register pair in one asm block (no s_nop pads), 2 = and no OR
                                          // over the pairs. Fewer instructions, not faster (in-process A/B: +1 %, +2 %): the consumer waves are
@@ -446,6 +450,8 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
   const unsigned long long t_begin = DBG != 0 ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt_begin = DBG != 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  typedef float f32x4q __attribute__((ext_vector_type(4)));
+  const f32x4q zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // the event window moves on by one event (a quad at a time is refilled by a scalar load, one quad ahead)
 #define S5_EV_NEXT()                                                                                                     \
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     st_wave_fence();                                                                                                     \
     if constexpr (DBG == 4) t_wait += __builtin_amdgcn_s_memtime() - tw0;                                                \
     f32x16 acc[NJ];                                                                                                      \
+    f32x4q accq[NJ][4];                                                                                                  \
     /* fragment reads run PF steps ahead of the MFMAs that consume them (register ring of PF + 1 steps); the scheduling    \
        barriers keep hipcc from sinking the reads back to their use (it otherwise issues read, wait, MFMA in turn and a     \
        wave shows the LDS latency sixteen times per tile) */                                                              \
@@ -507,8 +514,17 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
       _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
         if constexpr (DBG == 7) { s5_pin8(bf[s % ((PFV) + 1)][nj]); acc[nj] = zero16; }                                       \
+        else if constexpr (S5_SHAPE16 != 0) {                                                                                \
+          /* lab (timing only, wrong results): the same FLOP as two 16x16x32 MFMAs on quarters of the accumulator */         \
+          accq[nj][(2 * s) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s < 2 ? zero4 : accq[nj][(2 * s) & 3], 0, 0, 0); \
+          accq[nj][(2 * s + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s < 2 ? zero4 : accq[nj][(2 * s + 1) & 3], 0, 0, 0); \
+        }                                                                                                                  \
         else acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s == 0 ? zero16 : acc[nj], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+    if constexpr (S5_SHAPE16 != 0) {                                                                                       \
+      _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[nj][r] = accq[nj][r >> 2][r & 3];                              \
     }                                                                                                                    \
     if constexpr (S5_PRIO != 0) __builtin_amdgcn_s_setprio(0);                                                           \
     s5_lds_done(acc[0], acc[NJ - 1]);                                                                                    \
