@@ -75,7 +75,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef S5_SHAPE16
 #define S5_SHAPE16 0                     // lab (timing only, wrong results): every 32x32x16 MFMA as two 16x16x32 MFMAs — does the other shape
-                                         // hold a higher clock under the power limit in THIS kernel?
+                                         // hold a higher clock under the power limit in THIS kernel? With DISTINCT operands for the two:
+                                         // -5 % (1.370 against 1.437 ms); with the same operands twice -24 % (the clock follows the data:
+                                         // repeated operands toggle less). A complete 16x16x32 kernel (a user over four lanes, two users per
+                                         // lane, class maxima in LDS) was written, passed the scorer tests and measured 0 .. +6 %: dropped.
 #endif
 #ifndef S5_LADDER
 #define S5_LADDER 0                      // lab: 1 = maximum + compare of a register pair in one asm block (no s_nop pads), 2 = and no OR
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
         else if constexpr (S5_SHAPE16 != 0) {                                                                                \
           /* lab (timing only, wrong results): the same FLOP as two 16x16x32 MFMAs on quarters of the accumulator */         \
           accq[nj][(2 * s) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s < 2 ? zero4 : accq[nj][(2 * s) & 3], 0, 0, 0); \
-          accq[nj][(2 * s + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s < 2 ? zero4 : accq[nj][(2 * s + 1) & 3], 0, 0, 0); \
+          accq[nj][(2 * s + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s % ((PFV) + 1)][nj], ufrag[(s + 3) % KS], s < 2 ? zero4 : accq[nj][(2 * s + 1) & 3], 0, 0, 0); \
         }                                                                                                                  \
         else acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s % ((PFV) + 1)][nj], ufrag[s], s == 0 ? zero16 : acc[nj], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
