@@ -922,6 +922,56 @@ def test_deferred_adam_with_the_sweep_of_the_optimizer_launch_is_bit_identical(n
     assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
 
 
+@pytest.mark.parametrize('every', [0, 16])
+def test_deferred_adamw_replay_of_idle_rows_is_bit_identical(every):
+    """The replay's short cut for rows whose first moment is exactly zero (csrc/optim.hip, adam_wave_is_idle: never touched, or idle
+    until 0.9^n has underflowed — `v *= beta2; p *= 1 - lr wd` instead of the square root and the divisions): rows that get one
+    small gradient at step 0 and nothing for 1,250 steps (their first moment passes through the denormals to zero on the way), rows
+    that are never touched, rows touched now and then; without and with the optimizer launch's sweep. Parameters and both moment
+    buffers BIT-identical to the dense optimizer stepping every row every step (train/trainer.py:62-68)."""
+    import sibrar_amd as S
+    from importlib import import_module
+    engine = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine')
+    R, D = 64, 80
+    g = torch.Generator().manual_seed(9)
+    w0 = torch.randn(R, D, generator=g) * 0.1
+    mods, opts = [], []
+    for _ in range(2):
+        m = torch.nn.Embedding(R, D)
+        with torch.no_grad():
+            m.weight.copy_(w0)
+        m.to(DEV)
+        mods.append(m)
+        opts.append(S.FusedOptimizer(m, 'adamw', lr=3e-3, weight_decay=1e-2))
+        opts[-1].zero_grad()
+    d = engine.DeferredTable(opts[1], mods[1].weight, 0, R * D, None)
+    d.SWEEP_EVERY = every
+    opts[1].deferred = d
+    rng = np.random.default_rng(6)
+    for t in range(1300):
+        if t == 0:
+            rows, scale = torch.arange(0, 10), 1e-3
+        elif t == 1250:
+            rows, scale = torch.arange(0, R - 8), 1.0                   # the last eight rows are never touched
+        elif t % 97 == 0:
+            rows, scale = torch.from_numpy(rng.integers(10, 30, size=4)).unique(), 1.0
+        else:
+            rows, scale = torch.from_numpy(rng.integers(30, 40, size=1)), 1.0
+        grad_rows = (torch.randn(len(rows), D, generator=g) * scale).to(DEV)
+        rows_dev = rows.to(DEV)
+        opts[0].zero_grad()
+        mods[0].weight.grad[rows_dev] = grad_rows
+        opts[0].step_flat()
+        ids32 = rows.to(torch.int32).to(DEV)
+        d.catch_up(ids32)
+        mods[1].weight.grad[rows_dev] = grad_rows
+        assert opts[1].step_flat(zero_grad=True, rows=ids32) is False
+    d.flush()
+    assert float(opts[0].m[:10 * D].abs().max()) > 0.0                   # (rows 0-9 were touched again at step 1250)
+    assert torch.equal(mods[1].weight.detach().cpu(), mods[0].weight.detach().cpu())
+    assert torch.equal(opts[1].m.cpu(), opts[0].m.cpu()) and torch.equal(opts[1].v.cpu(), opts[0].v.cpu())
+
+
 @pytest.mark.parametrize('W,Bu,k', [(1, 5, 3), (2, 300, 20), (8, 1000, 20), (8, 77, 32), (4, 50, 1)])
 def test_merge_topk_kernel_equals_the_host_merge(W, Bu, k):
     """sbr_merge_topk (item-sharded evaluation: the all-gathered per-shard lists) == parallel.merge_topk (torch formulation, pinned
