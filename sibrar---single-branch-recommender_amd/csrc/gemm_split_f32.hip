@@ -356,7 +356,7 @@ extern "C" int sbr_gemm_split_bnstats_f32(const float* A, long lda, const float*
 // With v_mfma_f32_32x32x2_f32 this product (45,824 x 128 x 768 at the bench's batch) is bound by the fp32 matrix pipe: 57 us of
 // pipe time, 96 us measured; here it needs 6 x 1/16 of that and reads 141 MB of feature rows.
 #ifndef PJ_ABL
-#define PJ_ABL 0                         // lab (timing only): 2 weight planes written once, 3 the first two A chunks only, 4 = 2 + 3
+#define PJ_ABL 0                         // lab (timing only): 2 weight planes written once, 3 the first two A chunks only, 4 = 2 + 3, 5 no A split
 #endif
 struct ProjArgs {
   const float* A; long lda; const int* a_idx;
@@ -452,6 +452,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       sp_u32x4 a0, a1, a2;
+      if constexpr (PJ_ABL == 5) {                                 // lab (timing only): no split of the A values — their bits as they are
+        a0 = __builtin_bit_cast(sp_u32x4, raw[s][0]);
+        a1 = __builtin_bit_cast(sp_u32x4, raw[s][1]);
+        a2 = a0 ^ a1;
+      } else
       sp_split8(raw[s][0], raw[s][1], a0, a1, a2);
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
