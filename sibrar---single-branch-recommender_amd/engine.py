@@ -474,7 +474,10 @@ class DeferredTable:
     ``flush`` before anybody else reads the table: the model's state_dict, its module-level forward (evaluation, autograd path), a
     dense optimizer step, ``FusedTrainStep.close``."""
 
-    SWEEP_EVERY = 16                 # every row is brought up to date at least every SWEEP_EVERY steps (0: no sweep)
+    # Sweep period W of the optimizer launch: every row is brought up to date at least every W steps (0: no sweep; None: chosen per
+    # table — 16, or more when 1 / 16 of the table per step would dwarf the dense part of the launch: the sweep's bytes stay within
+    # a quarter of the dense part's (at least 8 MB), W <= 1024. c2: 16 (19 MB per step beside 185 MB); c4's 1M x 256 table: 768).
+    SWEEP_EVERY = None
 
     def __init__(self, opt, param: torch.Tensor, lo: int, hi: int, rowmap: Optional[torch.Tensor]):
         n_rows, D = param.shape
@@ -498,6 +501,13 @@ class DeferredTable:
         if opt.step_count > 0:       # steps taken densely before this object existed: every row is current
             self.last.fill_(opt.step_count)
             self.flushed_to = opt.step_count
+
+    def sweep_period(self) -> int:
+        if self.SWEEP_EVERY is not None:
+            return int(self.SWEEP_EVERY)
+        table = self.hi - self.lo
+        dense_bytes = 28.0 * (self.opt.fp.total - table)
+        return int(min(1024, max(16, -(-24.0 * table // max(0.25 * dense_bytes, 8e6)))))
 
     def _grow_sched(self, step: int):
         if step >= self.sched.shape[0]:
@@ -540,8 +550,9 @@ class DeferredTable:
         fp = o.fp
         # the sweep needs the claims of this step's catch-up (same ids) to tell the batch's rows from the others
         n_sweep = 0
-        if self.SWEEP_EVERY > 0 and self.sweep_ok and self._caught == o.step_count:
-            n_sweep = -(-self.n_q // self.SWEEP_EVERY)
+        every = self.sweep_period()
+        if every > 0 and self.sweep_ok and self._caught == o.step_count:
+            n_sweep = -(-self.n_q // every)
         sweep_lo = self._cursor
         self._cursor = (self._cursor + n_sweep) % self.n_q
         call('sbr_adam_step_rows', self.kind, ptr(fp.flat), ptr(fp.grad), ptr(o.m), ptr(o.v), fp.total, self.lo, self.hi, self.D, ptr(ids64),

@@ -61,6 +61,10 @@ CFGS = {
                loss='bpr', batch=256),
 }
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
+SWEEPS = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--sweep=')]      # lab: sweep period of the deferred table (0: none)
+if SWEEPS:
+    from importlib import import_module
+    import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine').DeferredTable.SWEEP_EVERY = SWEEPS[0]
 TRAIN_ONLY = '--train-only' in sys.argv
 BATCHES = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--batch=')]
 which = args or list(CFGS)
