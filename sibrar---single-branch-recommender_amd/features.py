@@ -161,6 +161,12 @@ class DeviceTable(nn.Module):
                              persistent=False)
         self._transposed = None
 
+    def n_entries(self) -> int:
+        """Stored entries of a 'csr' feature / real (non-padding) tags of a 'tag' feature (cached)."""
+        if getattr(self, '_n_entries', None) is None:
+            self._n_entries = int(self.indices.numel()) if self.kind == 'csr' else int((self.tags != self.pad).sum())
+        return self._n_entries
+
     def transposed(self, n_cols=None):
         """CSR form of the TRANSPOSED matrix of a 'csr' feature, on its device: (indptr int64 [dim + 1], indices int32 [nnz] = entity
         rows, data float32 [nnz] or None). Built once, on first use (the gather form of the projector's backward pass).

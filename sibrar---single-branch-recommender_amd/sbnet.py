@@ -186,11 +186,20 @@ class FeatureEmbedding(nn.Module):
     """algorithms/sgd_alg.py:1279-1396: per-feature front end. dense / CSR features -> PolyLinear projector (activation on
     the output too), categorical -> nn.Embedding, tag -> nn.EmbeddingBag(mean, padding)."""
 
-    # CSR modality, backward pass of the projector: gather form (sbr_csr_project_bwd_gather) when the step has at least n_entities /
-    # CSR_GATHER_MIN_FRACTION slots of the modality (fewer: the scatter form's atomics are cheaper than reading every nnz) and the
-    # per-entity workspace stays below CSR_GATHER_MAX_WS floats
-    CSR_GATHER_MIN_FRACTION = 8
+    # CSR / tag modality, weight gradient: gather form (sbr_csr_project_bwd_gather) or scatter form, by a cost model per column of the
+    # gradient — scatter: one float atomic per (slot, entry) at ~3.3 ps; gather: every entry of the matrix read once (~0.6 ps), one
+    # atomic per slot, the per-entity workspace zeroed (~0.7 ps per entity) and two more launches. Onion18: the CSR projector takes
+    # the gather form from ~2,500 slots (batch 4096: 30,805 slots, 1.25 -> 0.21 ms; batch 256: 1,877 slots, scatter form 76 us
+    # against 93), the tag bag from ~9,000. CSR_GATHER_FORCE (tests): True / False overrides the model.
+    CSR_GATHER_FORCE = None
     CSR_GATHER_MAX_WS = 1 << 28
+
+    def _gather_pays(self, n: int, nnz: int, n_entities: int, C: int) -> bool:
+        if self.CSR_GATHER_FORCE is not None:
+            return bool(self.CSR_GATHER_FORCE)
+        scatter = 3.3 * n * (nnz / max(n_entities, 1))
+        gather = 0.6 * nnz + 3.3 * n + 0.7 * n_entities + 12e6 / C
+        return scatter > gather
 
 
     def __init__(self, feature, embedding_dim: int = None, pre_embedding_layers: List[int] = None,
@@ -323,8 +332,8 @@ class FeatureEmbedding(nn.Module):
         if self.kind == 'tag':
             dW = torch.zeros_like(p[0]) if grad_out is None else grad_out[0]
             C = dout.shape[1]
-            if (n * self.CSR_GATHER_MIN_FRACTION >= t.n_rows and C % 4 == 0 and C <= 1024 and dW.stride(0) % 4 == 0
-                    and dW.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS):
+            if (C % 4 == 0 and C <= 1024 and dW.stride(0) % 4 == 0 and dW.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS
+                    and self._gather_pays(n, t.n_entries(), t.n_rows, C)):
                 # the mean over a tag list is a product with X[entity, tag] = 1 / (tags of the entity): the gather form of the CSR
                 # projector's backward pass (per-entity sums, then every tag gathers its entities' rows) serves it as it is
                 ti, tj, tv = t.transposed(dW.shape[0])
@@ -369,8 +378,8 @@ class FeatureEmbedding(nn.Module):
                 else:
                     dWt = torch.zeros(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
                 C = W.shape[0]
-                if (n * self.CSR_GATHER_MIN_FRACTION >= t.n_rows and C % 4 == 0 and C <= 1024 and dWt.stride(0) % 4 == 0
-                        and dWt.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS):
+                if (C % 4 == 0 and C <= 1024 and dWt.stride(0) % 4 == 0 and dWt.data_ptr() % 16 == 0 and t.n_rows * C <= self.CSR_GATHER_MAX_WS
+                        and self._gather_pays(n, t.n_entries(), t.n_rows, C)):
                     # many slots: add the slot gradients up per entity first, then every feature column gathers the rows of the
                     # entities that have it (the forward kernel over the transposed matrix; no atomics on the weight gradient)
                     ti, tj, tv = t.transposed()

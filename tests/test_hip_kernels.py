@@ -711,8 +711,9 @@ def test_front_backward_of_sparse_modalities_gather_form_equals_scatter_form(kin
     dout = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(1)).to(DEV)
     out = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(2)).abs().to(DEV) + 0.1  # positive: ReLU' = 1 everywhere
     got = {}
-    for form, frac in (('gather', 1 << 30), ('scatter', 0)):
-        fe.CSR_GATHER_MIN_FRACTION = frac
+    assert fe._gather_pays(30805, 326_000, 13610, 512) and not fe._gather_pays(1877, 326_000, 13610, 512)      # Onion18 at batch 4096 / 256
+    for form, force in (('gather', True), ('scatter', False)):
+        fe.CSR_GATHER_FORCE = force
         hidden = [] if kind == 'tag' else [out]
         grads = fe.front_backward(p, hidden, rows, n, out, dout, slots)
         got[form] = grads[0].detach().double().cpu()
