@@ -223,6 +223,7 @@ __global__ void infonce_kernel(const float* __restrict__ A, const float* __restr
 // lanes take the (i, j) pairs for the logits, rows / columns for the log-sum-exps, and COLUMNS for the backward products
 // dA = G B, dB = G^T A (G from LDS, broadcast). N <= 16, D <= 256, D % 4 == 0, 16-byte aligned rows.
 #define INF_S_MAXN 16
+#define INF_S_GPW(BWD) ((BWD) ? 1 : 4)       // groups per wave: the forward pass amortises its loss atomic, the backward pass wants the waves
 #define INF_S_MAXD 256
 template <bool BWD>
 __global__ __launch_bounds__(256) void infonce_small_kernel(const float* __restrict__ A, const float* __restrict__ Bm, long ld, long G,
@@ -231,9 +232,13 @@ __global__ __launch_bounds__(256) void infonce_small_kernel(const float* __restr
                                                             float* __restrict__ dB, long ldg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long g = (long)blockIdx.x * 4 + wave;
-  if (g >= G) return;                                           // wave-uniform; no workgroup barrier below
   const int LD = D + 4, LN = N + 1;
+  double loss_acc = 0.0;                                        // forward: this wave's groups
+  // a forward wave takes INF_S_GPW groups one after the other (its LDS region is its own: wave barriers only inside the loop): the forward
+  // pass then adds ONE double per workgroup to the loss instead of one per group — 4,096 atomics on one address were 40 us
+  for (int it = 0; it < INF_S_GPW(BWD); ++it) {
+  const long g = ((long)blockIdx.x * INF_S_GPW(BWD) + it) * 4 + wave;
+  if (g >= G) break;                                            // wave-uniform
   float* a = sm + (size_t)wave * (2 * N * LD + N * LN + 2 * N + 2);
   float* b = a + N * LD;
   float* L = b + N * LD;                                        // [N][N + 1]
@@ -277,10 +282,7 @@ __global__ __launch_bounds__(256) void infonce_small_kernel(const float* __restr
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if constexpr (!BWD) {
-    double acc = lane < N ? (double)(lse_r[lane] - L[lane * LN + lane]) + (double)(lse_c[lane] - L[lane * LN + lane]) : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) atomicAdd(loss_out, acc * scale);
+    loss_acc += lane < N ? (double)(lse_r[lane] - L[lane * LN + lane]) + (double)(lse_c[lane] - L[lane * LN + lane]) : 0.0;
   } else {
     const float up = gout[0] * (float)scale * inv_tau;
     for (int p = lane; p < N * N; p += 64) {
@@ -309,6 +311,16 @@ __global__ __launch_bounds__(256) void infonce_small_kernel(const float* __restr
       }
     }
   }
+  // the next group reuses this wave's LDS region
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if constexpr (!BWD) {
+    __shared__ double red[4];
+    const double t = block_sum_d(loss_acc, red);                // every wave of the workgroup arrives here
+    if (threadIdx.x == 0) atomicAdd(loss_out, t * scale);
+  }
 }
 static bool infonce_small_ok(const float* A, const float* B, long ld, int N, int D, const float* dA, const float* dB, long ldg) {
   return N <= INF_S_MAXN && D <= INF_S_MAXD && (D & 3) == 0 && (ld & 3) == 0 && (ldg & 3) == 0 &&
@@ -333,7 +345,7 @@ extern "C" int sbr_infonce_fwd(const float* A, const float* B, long ld, long G, 
   if (infonce_small_ok(A, B, ld, N, D, nullptr, nullptr, 0)) {
     const int ls = infonce_small_lds(N, D);
     if (ls > 64 * 1024) (void)hipFuncSetAttribute((const void*)infonce_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ls);
-    infonce_small_kernel<false><<<(unsigned)sbr_cdiv(G, 4), 256, ls, s>>>(A, B, ld, G, N, D, 1.f / tau, scale, loss_out, nullptr, nullptr, nullptr, 0);
+    infonce_small_kernel<false><<<(unsigned)sbr_cdiv(G, 4 * INF_S_GPW(false)), 256, ls, s>>>(A, B, ld, G, N, D, 1.f / tau, scale, loss_out, nullptr, nullptr, nullptr, 0);
     SBR_CHECK_LAUNCH("sbr_infonce_fwd (small groups)");
     return SBR_OK;
   }
@@ -352,7 +364,7 @@ extern "C" int sbr_infonce_bwd(const float* A, const float* B, long ld, long G, 
   if (infonce_small_ok(A, B, ld, N, D, dA, dB, ldg)) {
     const int ls = infonce_small_lds(N, D);
     if (ls > 64 * 1024) (void)hipFuncSetAttribute((const void*)infonce_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ls);
-    infonce_small_kernel<true><<<(unsigned)sbr_cdiv(G, 4), 256, ls, (hipStream_t)stream>>>(A, B, ld, G, N, D, 1.f / tau, scale, nullptr, grad_out, dA, dB, ldg);
+    infonce_small_kernel<true><<<(unsigned)sbr_cdiv(G, 4 * INF_S_GPW(true)), 256, ls, (hipStream_t)stream>>>(A, B, ld, G, N, D, 1.f / tau, scale, nullptr, grad_out, dA, dB, ldg);
     SBR_CHECK_LAUNCH("sbr_infonce_bwd (small groups)");
     return SBR_OK;
   }
