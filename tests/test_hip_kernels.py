@@ -711,7 +711,8 @@ def test_front_backward_of_sparse_modalities_gather_form_equals_scatter_form(kin
     dout = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(1)).to(DEV)
     out = torch.randn(n + 50, C, generator=torch.Generator().manual_seed(2)).abs().to(DEV) + 0.1  # positive: ReLU' = 1 everywhere
     got = {}
-    assert fe._gather_pays(30805, 326_000, 13610, 512) and not fe._gather_pays(1877, 326_000, 13610, 512)      # Onion18 at batch 4096 / 256
+    assert fe._gather_pays(30805, 326_000, 13610, 5192, 512) and not fe._gather_pays(1877, 326_000, 13610, 5192, 512)      # Onion18 at batch 4096 / 256
+    assert fe._gather_pays(45056, 6600, 3299, 19, 64) and not fe._gather_pays(2816, 6600, 3299, 19, 64)                   # ML-1M's 18 genre tags: the adds on one row serialise
     for form, force in (('gather', True), ('scatter', False)):
         fe.CSR_GATHER_FORCE = force
         hidden = [] if kind == 'tag' else [out]
