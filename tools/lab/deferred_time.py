@@ -10,7 +10,7 @@ from importlib import import_module
 engine = import_module(S.ops.__name__.rsplit('.', 1)[0] + '.engine')
 DEV = 'cuda'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-R, D, REST = 100_000, 128, 6_500_000
+R, D, REST = int(os.environ.get('DT_R', 100_000)), int(os.environ.get('DT_D', 128)), int(os.environ.get('DT_REST', 6_500_000))
 
 
 class M(torch.nn.Module):
