@@ -37,7 +37,8 @@
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef S5_NL
-#define S5_NL 2                          // loader waves per workgroup
+#define S5_NL 1                          // loader waves per workgroup (a tile period is ~2 us with 12-13 consumer waves, one wave's LDS-DMA
+                                         // stream fills a 16 KB tile in 0.65 us; two loader waves measured 1 % slower with S5_PRIO 3)
 #endif
 #define S5_MAXW (16 - S5_NL)             // consumer waves per workgroup (+ the loader waves = 1024 threads)
 #ifndef S5_PF1
@@ -47,7 +48,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define S5_PF2 1                         // ... with two (D = 64, 128)
 #endif
 #ifndef S5_PRIO
-#define S5_PRIO 0                        // s_setprio level of a consumer wave while it issues a tile's MFMAs (0: none)
+#define S5_PRIO 3                        // s_setprio level of a consumer wave while it issues a tile's MFMAs (0: none; 3: -1 % in the
+                                         // in-process A/B at D = 128 and 256 once no SIMD carries a fourth consumer wave)
 #endif
 #ifndef S5_NS
 #define S5_NS 6                          // LDS ring slots of 16 KB (D = 128: 64-item tiles, D = 256: 32-item tiles)
