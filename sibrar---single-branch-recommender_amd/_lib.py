@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libsibrar_hip.so')
 if os.environ.get('SBR_LAB_LIB'):        # lab: a kernel variant built by tools/lab/build_*_variants.sh (never set in product runs)
     LIB_PATH = os.path.abspath(os.environ['SBR_LAB_LIB'])
+    import sys as _sys
+    print(f'[sibrar_amd] SBR_LAB_LIB is set: loading the LAB library {LIB_PATH} instead of the product library — lab builds carry '
+          f'timing-only ablation switches; never use one for results', file=_sys.stderr, flush=True)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'sibrar_hip.h')
 
 

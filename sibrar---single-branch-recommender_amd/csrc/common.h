@@ -90,6 +90,14 @@ __device__ __forceinline__ float sbr_wave_max(float v) {
 
 static inline int sbr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute configures the CURRENT device's copy of a kernel: `slot` (one static per kernel instantiation) remembers the device
+// it was last configured on, so a process that drives several GPUs configures each of them (a plain "done" flag would skip the second)
+static inline bool sbr_attr_stale(int* slot) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || *slot != dev) { *slot = dev; return true; }
+  return false;
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Column reductions over an [n, D] row-major matrix with D % 4 == 0 (column sums of bias gradients, BatchNorm statistics).

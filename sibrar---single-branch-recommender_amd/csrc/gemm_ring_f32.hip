@@ -395,13 +395,12 @@ static int ring_launch(GemmArgs& g, hipStream_t s) {
   const int n_items = g.mt * g.nt * g.splits;
   const size_t lds = (size_t)NS * (BM + BN) * RK * 4 + (A_KM ? 2 * RING_IDX_CAP * 4 : RING_BIAS_CAP * 4);
   auto kern = gemm_ring_kernel<MI, A_KM, B_KN, NS>;
-  static bool attr_set = false;                                // per instantiation
-  if (!attr_set) {
+  static int attr_dev = -1;
+  if (sbr_attr_stale(&attr_dev)) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       sbr_set_error("sbr_gemm_f32(ring): cannot raise the dynamic LDS limit to %zu", lds);
       return SBR_ERR_HIP;
     }
-    attr_set = true;
   }
   const int per_cu = (int)(160 * 1024 / lds);
   int grid = 256 * per_cu;

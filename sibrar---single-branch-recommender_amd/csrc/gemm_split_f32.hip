@@ -307,13 +307,12 @@ static int gemm_split_impl(int mode, const float* A, long lda, const float* W, l
   hipStream_t s = (hipStream_t)stream;
 #define SP_LAUNCH(MODE, EPI)                                                                                              \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static int attr_dev = -1;                                                                                          \
+    if (sbr_attr_stale(&attr_dev)) {                                                                                                       \
       if (hipFuncSetAttribute((const void*)gemm_split_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
         sbr_set_error("sbr_gemm_split_f32: cannot raise the dynamic LDS limit");                                           \
         return SBR_ERR_HIP;                                                                                                \
       }                                                                                                                    \
-      attr_set = true;                                                                                                     \
     }                                                                                                                      \
     gemm_split_kernel<MODE, EPI><<<grid, 64 * SP_WAVES, lds, s>>>(g, n_blocks);                                            \
   } while (0)
@@ -580,13 +579,12 @@ extern "C" int sbr_gemm_split_proj_f32(const float* A, long lda, const int* a_id
   int grid = sbr_cdiv(n_blocks, 4);                              // one block per SIMD first: the second wave of a SIMD only adds
   if (grid > 256) grid = 256;                                    // matrix-pipe time to it (see the work-item note in the kernel)
   const size_t lds = 2 * PJ_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_dev = -1;
+  if (sbr_attr_stale(&attr_dev)) {
     if (hipFuncSetAttribute((const void*)gemm_split_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       sbr_set_error("sbr_gemm_split_proj_f32: cannot raise the dynamic LDS limit");
       return SBR_ERR_HIP;
     }
-    attr_set = true;
   }
   gemm_split_proj_kernel<<<grid, 64 * SP_WAVES, lds, (hipStream_t)stream>>>(g, n_blocks);
   SBR_CHECK_LAUNCH("sbr_gemm_split_proj_f32");

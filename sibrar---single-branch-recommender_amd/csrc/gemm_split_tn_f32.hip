@@ -368,13 +368,12 @@ int sbr_tn_split_launch(const float* A, long lda, const int* a_idx, const float*
   const int grid = sbr_cdiv(nz * g.nj * g.nm, 8) * 8;
 #define TS_LAUNCH(WIDE)                                                                                                   \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static int attr_dev = -1;                                                                                          \
+    if (sbr_attr_stale(&attr_dev)) {                                                                                                       \
       if (hipFuncSetAttribute((const void*)gemm_split_tn_kernel<WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
         sbr_set_error("sbr_gemm_tn_f32: cannot raise the dynamic LDS limit of the bf16-split kernel");                     \
         return SBR_ERR_HIP;                                                                                                \
       }                                                                                                                    \
-      attr_set = true;                                                                                                     \
     }                                                                                                                      \
     gemm_split_tn_kernel<WIDE><<<grid, 512, lds, s>>>(g);                                                                  \
   } while (0)

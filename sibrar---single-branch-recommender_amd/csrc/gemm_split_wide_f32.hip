@@ -260,13 +260,12 @@ extern "C" int sbr_gemm_split_wide_f32(int mode, const float* A, long lda, const
   int grid = n_groups * n_cb;
   if (grid > 256) grid = 256;
   const size_t lds = 2 * SW_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_dev = -1;
+  if (sbr_attr_stale(&attr_dev)) {
     if (hipFuncSetAttribute((const void*)gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       sbr_set_error("sbr_gemm_split_wide_f32: cannot raise the dynamic LDS limit");
       return SBR_ERR_HIP;
     }
-    attr_set = true;
   }
   gemm_split_wide_kernel<<<grid, 64 * SW_WAVES, lds, (hipStream_t)stream>>>(g, n_groups, n_cb);
   SBR_CHECK_LAUNCH("sbr_gemm_split_wide_f32");

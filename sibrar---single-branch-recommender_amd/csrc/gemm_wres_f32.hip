@@ -272,13 +272,12 @@ extern "C" int sbr_gemm_wres_f32(int mode, const float* A, long lda, const float
   hipStream_t s = (hipStream_t)stream;
 #define WR_LAUNCH(MODE, EPI)                                                                                              \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
+    static int attr_dev = -1;                                                                                          \
+    if (sbr_attr_stale(&attr_dev)) {                                                                                                       \
       if (hipFuncSetAttribute((const void*)gemm_wres_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
         sbr_set_error("sbr_gemm_wres_f32: cannot raise the dynamic LDS limit");                                            \
         return SBR_ERR_HIP;                                                                                                \
       }                                                                                                                    \
-      attr_set = true;                                                                                                     \
     }                                                                                                                      \
     gemm_wres_kernel<MODE, EPI><<<grid, 256, lds, s>>>(g, n_tiles);                                                        \
   } while (0)

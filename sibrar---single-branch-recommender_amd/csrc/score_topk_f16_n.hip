@@ -640,7 +640,40 @@ __global__ __launch_bounds__(1024) void score_topk_f16_n_kernel(
     if constexpr (DBG == 3) t_issue += t_mid - ti0;
     const unsigned long long ti1 = DBG == 4 ? __builtin_amdgcn_s_memtime() : 0ull;
     if constexpr (DBG == 4) t_issue += ti1 - ti0 - (__builtin_amdgcn_s_memtime() - ti1);
-    if constexpr (DBG == 1 || DBG >= 5) {
+    if constexpr (DBG == 8 || DBG == 9) {
+      // lab (timing only): the class-maxima-only main pass of a two-pass scorer — per tile one v_max3 per accumulator register pair
+      // into the lane's 16 class maxima, stored and reset every ST_X tiles (a group = one register class over ST_X tiles = 64 items);
+      // 9: with the exclusion bits applied first
+      constexpr int ST_X = NJ == 2 ? 32 : 64;
+      if constexpr (DBG == 9) {
+        if (have_ex) {
+          const unsigned int ex0 = ex;
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nj][r] = ((ex0 >> (nj * 16 + r)) & 1u) ? -INFINITY : acc[nj][r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (NJ == 2) cm[r] = __builtin_fmaxf(cm[r], __builtin_fmaxf(acc[0][r], acc[1][r]));
+        else cm[r] = fmaxf(cm[r], acc[0][r]);
+      }
+      if ((tl & (ST_X - 1)) == ST_X - 1 || tl == n_tiles - 1) {
+        const int n_st = (n_tiles + ST_X - 1) / ST_X;
+        f32x4q* o = reinterpret_cast<f32x4q*>(gbuf) + (((brow0 >> 5) * n_st + tl / ST_X) * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4q v = {cm[4 * q], cm[4 * q + 1], cm[4 * q + 2], cm[4 * q + 3]};
+          o[q * 64] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[r] = -INFINITY;
+      }
+      continue;
+    }
+    if constexpr (DBG == 1 || (DBG >= 5 && DBG <= 7)) {
       s5_pin(acc[0], acc[NJ - 1]);
       continue;
     }
@@ -1085,13 +1118,11 @@ static int s5_build_events(void* buf, long buf_bytes, long Bu, int I, const long
   if (hipMemsetAsync(gc, 0, G * 4, s) != hipSuccess) { sbr_set_error("sbr_score_topk_f16: memset failed"); return SBR_ERR_HIP; }
   s5_ev_rows_kernel<<<(unsigned int)sbr_cdiv(Bu, 256), 256, 0, s>>>(Bu, u_idx, eptr, eidx, item_offset, I, rl, rc, gc);
   s5_ev_scan_kernel<<<1, 1024, 0, s>>>((int)G, gc, gb);
-  static bool lds_raised = false;
-  if (!lds_raised) {
-    if (hipFuncSetAttribute((const void*)s5_ev_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-      sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit of the event builder");
-      return SBR_ERR_HIP;
-    }
-    lds_raised = true;
+  // (set on every build: the attribute belongs to the current device's copy of the kernel, a process-wide flag would skip the second GPU
+  // of a multi-device process; building the stream happens once per evaluation split)
+  if (hipFuncSetAttribute((const void*)s5_ev_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+    sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit of the event builder");
+    return SBR_ERR_HIP;
   }
   s5_ev_scatter_kernel<<<(unsigned int)G, 256, (size_t)n_tiles_ev * 4, s>>>(Bu, eidx, item_offset, tile_items, n_tiles_ev, rl, rc, gc, gb, ev, cap);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16 (exclusion events)");
@@ -1107,7 +1138,12 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
   const long n_wg = plan.n_wg;
   const long padded = s5_padded_users(Bu);
   const long buf_bytes = padded * 2 * S5_CAPH * 8, cnt_bytes = s5_al16(padded * 2 * 8);
-  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;      // 1 | 2 | 5 | 6 | 7: timing-only ablations, 4: cycle stamps
+#ifdef SBR_LAB
+  // lab builds only (tools/lab/build_scorer_variants.sh defines SBR_LAB; output under tools/lab/bin/): timing-only ablations of the
+  // kernel (1 | 2 | 5 | 6 | 7 | 8 | 9: results are garbage by design) and cycle stamps (3 | 4). The product library compiles the
+  // DBG = 0 kernel only and reads no environment variable on a launch path.
+  const int dbg = getenv("SBR_ST_DEBUG") ? atoi(getenv("SBR_ST_DEBUG")) : 0;
+#endif
   SBR_REQUIRE(n_wg * 32L * W + 32L * plan.n_part <= padded && sbr_cdiv(Bu, 32) * 32 + 32L * plan.n_part <= padded, "sbr_score_topk_f16: internal: padding");
   SBR_REQUIRE(workspace && workspace_bytes >= s5_workspace_bytes(Bu),
               "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given", s5_workspace_bytes(Bu), workspace_bytes);
@@ -1126,13 +1162,20 @@ static int s5_launch(const void* U, const void* It, long Bu, int I, const long* 
   // 8: 1.59, 16: 1.54, 32: 1.55, 65: 1.58); SBR_ST_PRE overrides (tiles, lab)
   const int n_tiles = sbr_cdiv(I, 32 * NJ);
   int n_pre = n_tiles >= 96 ? S5_PRE_TILES : 0;
+#ifdef SBR_LAB
   if (getenv("SBR_ST_PRE")) n_pre = atoi(getenv("SBR_ST_PRE"));
+#endif
   if (n_pre > n_tiles) n_pre = n_tiles;
   if (n_pre < 0 || !PRE) n_pre = 0;
+#ifdef SBR_LAB
   auto kern = dbg == 1 ? score_topk_f16_n_kernel<KS, NS, NJ, 1, PRE> : (dbg == 2 ? score_topk_f16_n_kernel<KS, NS, NJ, 2, PRE> :
               (dbg == 4 ? score_topk_f16_n_kernel<KS, NS, NJ, 4, PRE> : (dbg == 3 ? score_topk_f16_n_kernel<KS, NS, NJ, 3, PRE> : (dbg == 5 ? score_topk_f16_n_kernel<KS, NS, NJ, 5, PRE> :
               (dbg == 6 ? score_topk_f16_n_kernel<KS, NS, NJ, 6, PRE> : (dbg == 7 ? score_topk_f16_n_kernel<KS, NS, NJ, 7, PRE> :
-               score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>))))));
+              (dbg == 8 ? score_topk_f16_n_kernel<KS, NS, NJ, 8, PRE> : (dbg == 9 ? score_topk_f16_n_kernel<KS, NS, NJ, 9, PRE> :
+               score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>))))))));
+#else
+  auto kern = score_topk_f16_n_kernel<KS, NS, NJ, 0, PRE>;
+#endif
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     sbr_set_error("sbr_score_topk_f16: cannot raise the dynamic LDS limit to %zu", lds);
     return SBR_ERR_HIP;

@@ -639,8 +639,19 @@ class FusedTrainStep:
             if table.dim() == 2 and table.stride() == (table.shape[1], 1) and hi - lo == table.numel():
                 self.deferred = DeferredTable(optimizer, table, lo, hi, fe._table.rowmap)
                 optimizer.deferred = self.deferred
+                # Readers AND writers of the table outside the fused step see / leave a current table: state_dict() and the
+                # module-level forward flush first; load_state_dict() (Trainer / load_model_from_path, on the net or on the user
+                # module alone) flushes BEFORE the copy — the zero-gradient steps a row still owes belong to the OLD weights and
+                # moments, replayed after the copy they would decay and step the loaded weights — and marks every row current after
+                # it. (An in-place edit of the parameter's storage by other code cannot be intercepted: call flush() first.)
+                def _loaded(*a, **k):
+                    if self.deferred is not None:
+                        self.deferred.mark_all_current()
                 self._hooks = [net.register_state_dict_pre_hook(lambda *a, **k: self.flush()),
                                fe.register_forward_pre_hook(lambda *a, **k: self.flush())]
+                for mod in (net, fe):
+                    self._hooks.append(mod.register_load_state_dict_pre_hook(lambda *a, **k: self.flush()))
+                    self._hooks.append(mod.register_load_state_dict_post_hook(_loaded))
 
     def draw(self, u_shape, i_shape):
         """Modality draws of one step (user side first, as in SingleBranchNet.forward). May be called from the loader

@@ -241,7 +241,7 @@ class FullEvaluator:
 
 
 def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, device='cuda', return_raw=False, verbose=False,
-                                   scorer: str = 'fp32', user_chunk: Optional[int] = None):
+                                   scorer: str = 'fp32', user_chunk: Optional[int] = None, shard_items: bool = False):
     """eval/eval.py:171-227 (SGD branch :203-222). ``eval_loader`` only has to expose ``dataset`` and ``batch_size``.
 
     The users are scored in engine-sized chunks, not in the loader's batches: per-user results do not depend on the grouping,
@@ -249,8 +249,10 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     c2, 100k users, first kernel: 975 ms with 256-user batches, 37 ms with 8192, 12 ms in one launch); the fp32 path is bounded by the [chunk, items] score
     matrix it materialises. ``user_chunk`` overrides the choice.
 
-    **Item-sharded under an initialised process group** (new: SURVEY.md 8(e), BASELINE configs[4] — the reference has no multi-GPU
-    path): rank r computes the representations of items [lo_r, hi_r) of the split only and scores every user chunk against them
+    **Item-sharded on request** (``shard_items=True`` under an initialised process group; new: SURVEY.md 8(e), BASELINE configs[4] —
+    the reference has no multi-GPU path; ``Trainer.val`` opts in, a rank-0-only evaluation simply does not): EVERY rank of the group
+    must make the same call on the same split (the routine runs collectives; the ranks first check that they agree on the split's item
+    and user lists and raise otherwise instead of hanging or merging lists of different users). Rank r computes the representations of items [lo_r, hi_r) of the split only and scores every user chunk against them
     (fused kernel with ``item_offset``, or fp32 GEMM + shard-aware mask + top-k); the per-shard ``[Bu, k]`` (score, item position)
     lists are all-gathered and merged exactly (``parallel.all_gather_topk`` -> ``sbr_merge_topk``: score desc, index asc), and every
     rank feeds the merged lists to its evaluator — all ranks return the same metrics as a one-rank evaluation. Models whose item side
@@ -264,9 +266,19 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
     with torch.no_grad():
         items = torch.as_tensor(np.asarray(dataset.items_in_split)).to(device)
         n_split = int(items.shape[0])
-        world = parallel.world_size() if parallel.is_distributed() else 1
+        world = parallel.world_size() if (shard_items and parallel.is_distributed()) else 1
         lo, hi = 0, n_split
         sharded = False
+        users = np.asarray(dataset.users_in_split)
+        if world > 1:
+            # all ranks must be evaluating the same split: (items, users, sum of user ids, sum of item ids) agree or nobody shards
+            fp = torch.tensor([n_split, len(users), int(users.astype(np.int64).sum()), int(items.sum())], device=device, dtype=torch.int64)
+            fp_lo, fp_hi = fp.clone(), fp.clone()
+            torch.distributed.all_reduce(fp_lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(fp_hi, op=torch.distributed.ReduceOp.MAX)
+            if not bool((fp_lo == fp_hi).all()):
+                raise ValueError(f'evaluate_recommender_algorithm(shard_items=True): the ranks evaluate different splits '
+                                 f'(items / users / id sums: this rank {fp.tolist()}, min {fp_lo.tolist()}, max {fp_hi.tolist()})')
         if world > 1 and (world - 1) * (-(-n_split // world)) < n_split:      # every rank gets a non-empty shard
             rank = torch.distributed.get_rank()
             lo, hi = parallel.item_shard(n_split, rank, world)
@@ -287,7 +299,6 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
                 dataset._excl_dev = excl
             except Exception:
                 pass
-        users = np.asarray(dataset.users_in_split)
         bs = int(getattr(eval_loader, 'batch_size', 256) or 256)
         if scorer not in ('fp32', 'fp16_fused'):
             raise ValueError(f'unknown scorer {scorer!r}')
@@ -317,7 +328,11 @@ def evaluate_recommender_algorithm(alg, eval_loader, evaluator: FullEvaluator, d
                         dataset._scorer_excl = cache
                     except Exception:
                         pass
-                holder = cache.setdefault((s, int(u_idxs.numel()), lo, hi, int(i16.shape[1])), ops.ScorerExclusions())
+                # (the key carries a fingerprint of the chunk's user ids: a split whose users_in_split changed between two evaluations
+                # must not meet the mask of the old users)
+                chunk = users[s:s + bs].astype(np.int64)
+                holder = cache.setdefault((s, int(chunk.size), int(chunk[0]), int(chunk[-1]), int(chunk.sum()), lo, hi, int(i16.shape[1])),
+                                          ops.ScorerExclusions())
                 val, idx = ops.score_topk_f16(ops.cast_f16(u_repr), i16, kmax, u_idxs, excl[0], excl[1], item_offset=lo, exclusions=holder)
             else:
                 out = alg.combine_user_item_representations(u_repr, i_repr)

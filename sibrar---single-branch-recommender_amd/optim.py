@@ -70,13 +70,36 @@ class FusedOptimizer:
     def __init__(self, module: nn.Module, name: str = 'adamw', lr: float = 1e-3, weight_decay: float = 0.):
         if name not in ('adamw', 'adam', 'adagrad'):
             raise KeyError(name)
-        self.name, self.lr, self.wd = name, lr, weight_decay
+        self.deferred = None         # engine.DeferredTable of a fused step that updates one lookup table row by row
+        self.name, self._lr, self._wd = name, float(lr), float(weight_decay)
         self.fp = FlatParameters(module)
         self.step_count = 0
         n, dev = self.fp.total, self.fp.flat.device
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32) if name != 'adagrad' else None
-        self.deferred = None         # engine.DeferredTable of a fused step that updates one lookup table row by row
+
+    # lr / wd: a deferred table replays the zero-gradient steps its rows still owe with the hyper-parameters of the call that replays them
+    # (the per-step schedule keeps only the bias corrections), so every row is brought up to date BEFORE a hyper-parameter changes:
+    # the steps taken so far were taken with the old value on every row, exactly as the dense optimizer would have
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        if float(value) != self._lr and self.deferred is not None:
+            self.deferred.flush()
+        self._lr = float(value)
+
+    @property
+    def wd(self) -> float:
+        return self._wd
+
+    @wd.setter
+    def wd(self, value: float):
+        if float(value) != self._wd and self.deferred is not None:
+            self.deferred.flush()
+        self._wd = float(value)
 
     def _sync_grads(self):
         """Gradients that autograd produced as fresh tensors (instead of accumulating into the flat views) are copied in."""

@@ -16,6 +16,7 @@ import sys
 
 import torch
 
+from . import parallel
 from .evaluation import FullEvaluator, evaluate_recommender_algorithm
 from .optim import FusedOptimizer
 
@@ -168,8 +169,9 @@ class Trainer:
     def _eval_loader(self, loader, config, evaluator_name: str = None):
         self.model.eval()
         evaluator = FullEvaluator(config=config, evaluator_name=evaluator_name, dataset=loader.dataset)
+        # a data-parallel Trainer evaluates on every rank (fit() is collective): the catalogue is item-sharded over the ranks
         return evaluate_recommender_algorithm(self.pointer_to_model, loader, evaluator, self.device,
-                                              verbose=self.batch_verbose, scorer=self.scorer)
+                                              verbose=self.batch_verbose, scorer=self.scorer, shard_items=parallel.is_distributed())
 
     def train_val(self):
         return self._eval_loader(self.train_val_loader, _get(self.full_conf, 'train_eval'), 'train')

@@ -41,7 +41,8 @@ def run(S, DEV):
         for scorer in ('fp32', 'fp16_fused'):
             ev = S.FullEvaluator(config=S.evaluation._Cfg(top_k=ks, calculate_std=False), dataset=view)
             loader = type('L', (), {'dataset': view, 'batch_size': 64})()
-            metrics, raw = S.evaluate_recommender_algorithm(net, loader, ev, DEV, return_raw=True, scorer=scorer, user_chunk=1024)
+            metrics, raw = S.evaluate_recommender_algorithm(net, loader, ev, DEV, return_raw=True, scorer=scorer, user_chunk=1024,
+                                                            shard_items=True)
             for k, v in raw.items():
                 out[f'{name}/{scorer}/{k}'] = np.asarray(v)
             for k, v in metrics.items():
