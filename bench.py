@@ -37,6 +37,7 @@ PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_MFMA_F16 = 2500.0    # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM = 8000.0         # GB/s
 SETTLE = 30               # extra untimed steps after --warmup (see bench_training)
+TABLES = {}               # per-kernel tables: written to a side file (bench_tables.json), not into the one JSON line
 LAST_LOSS = {}            # batch size -> total loss of the last timed step
 EXCHANGE = {}             # batch size -> how the user-table gradient was exchanged (data-parallel runs)
 
@@ -372,9 +373,36 @@ def step_roofline(timings, steps, batch, n_params, deferred_table=0, table_dim=0
         out['selection'] = 'largest time per step over ALL kernels of the step (GEMM signatures and every other entry point)'
         if gemm is not None and out.get('kernel') != gemm.get('kernel'):
             out['dominant_gemm'] = gemm
-        out['all_gemms'] = gemm_table(timings, steps)
-        out['all_kernels'] = calls[:16]
+        TABLES['c2_step_all_gemms'] = gemm_table(timings, steps)
+        TABLES['c2_step_all_kernels'] = calls
     return out
+
+
+def compact_roofline(r):
+    """The roofline object of the line without prose: numbers, the kernel's name, where its traffic figure comes from."""
+    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'pipe_frac', 'hbm_frac', 'fp32_equivalent_tflops', 'algorithmic_bytes',
+            'algorithmic_flop', 'avg_launch_ms', 'launches', 'kernel_ms_per_step', 'gemm_ms_per_step', 'kernel', 'traffic_source')
+    out = {k: r[k] for k in keep if k in r and r[k] is not None or k == 'traffic' and k in r}
+    if isinstance(out.get('traffic_source'), str):
+        out['traffic_source'] = out['traffic_source'].split(' (rocprofv3')[0] + ('; STALE' + out['traffic_source'].split('STALE')[1] if 'STALE' in out['traffic_source'] else '')
+    if 'dominant_gemm' in r:
+        g = r['dominant_gemm']
+        out['dominant_gemm'] = {k: g[k] for k in ('kernel', 'bound', 'frac', 'pipe_frac', 'hbm_frac', 'avg_launch_ms', 'fp32_equivalent_tflops', 'traffic') if k in g}
+    out['timing'] = 'HIP events around every launch of K plain-launch steps after the timed region'
+    return out
+
+
+def write_tables():
+    """Per-kernel tables of this run (every GEMM signature and entry point of the c2 and c3 steps, priced like ``roofline``) -> side file;
+    returns its path relative to the repository (the line only names it)."""
+    path = os.path.join(ROOT, 'gpurun_out', 'bench_tables.json')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(TABLES, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        return f'not written ({e})'
 
 
 def _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm):
@@ -538,15 +566,25 @@ C1_MODEL = {'shared_common_dim': 64, 'user': {'feature_name': 'user_embedding', 
 
 
 C1_TRAIN_STEPS = 300      # recorded batches both sides train on before the evaluation that is compared
+C1_GPU_RUNS, C1_CPU_RUNS = 5, 3
+C1_SNAP = (1, 10, 100, 300)
+
+
+def _mean_sd(xs):
+    m = sum(xs) / len(xs)
+    return m, (sum((x - m) ** 2 for x in xs) / max(len(xs) - 1, 1)) ** 0.5
 
 
 def bench_c1(S, device, steps):
     """ML-1M-shaped synthetic data (U 5,816, I 3,299, 651k interactions drawn with Zipf(1) item popularity, 18 genre
     tags + 768-d text, C = D = 64, pairwise InfoNCE, BPR, AdamW) — BASELINE.md section 3: GPU interactions/s at the reference's batch
     256 and at 4096; the CPU port (oracle restatement: same torch-CPU ops, same per-row numpy sampling calls as the reference) timed on
-    the same inputs and parameters, cores stated; and "NDCG@10 equal to the CPU restatement on identical inputs" on a TRAINED model:
-    both sides take the same C1_TRAIN_STEPS recorded batches and modality draws from the same initial parameters
-    (train/trainer.py:204-223), then one full evaluation pass each (eval/eval.py:205-222: scores/s, NDCG@10)."""
+    the same inputs and parameters, cores stated; and "matched NDCG@10" as a MEASUREMENT: the GPU engine trains C1_GPU_RUNS times and
+    the CPU port C1_CPU_RUNS times on the SAME C1_TRAIN_STEPS recorded batches and modality draws from the SAME initial parameters
+    (train/trainer.py:204-223), every trained model is evaluated once (eval/eval.py:205-222), and the two means must lie within twice
+    the pooled standard deviation of the runs. Run-to-run differences on one side come from rounding only (GPU: float-atomic scatter
+    order; CPU: the runs use different thread counts, i.e. different reduction orders), which is exactly what separates the two sides.
+    The relative parameter distance between the sides after 1 / 10 / 100 / 300 steps shows the rounding-level start and its growth."""
     from oracle import eval_ref, losses_ref, model_ref, sampling_ref, train_ref
     ds = S.SyntheticDataset(C1['n_users'], C1['n_items'], C1['nnz'], item_dense={'text': 768}, item_tags={'genres': (18, 3)}, seed=0,
                             n_negative_samples=C1['n_neg'], negative_sampling_strategy='uniform_recbole', holdout_per_user=1,
@@ -557,83 +595,150 @@ def bench_c1(S, device, steps):
     sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     bpr = S.RecBayesianPersonalizedRankingLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
                                                neg_train=ds.n_negative_samples)
-    out = {'workload': 'BASELINE configs[0] shape: synthetic ML-1M (5,816 users x 3,299 items, ~650k interactions with Zipf(1) item '
-                       'popularity, 18 genre tags + 768-d text, C = D = 64, hidden [64], pairwise InfoNCE, BPR, 10 negatives, AdamW 1e-3 / '
-                       '1e-6), user = lookup'}
-    # ---- CPU port: trains C1_TRAIN_STEPS batches from the initial parameters; every batch and modality draw is recorded
+    out = {'workload': 'BASELINE configs[0] shape: synthetic ML-1M (5,816 x 3,299, ~650k interactions, Zipf(1) items, 18 genre tags + 768-d '
+                       'text, C = D = 64, hidden [64], pairwise InfoNCE, BPR, 10 negatives, AdamW 1e-3 / 1e-6), user = lookup'}
     cores = host_cores()
-    torch.set_num_threads(cores)
-    sd = {k: v.clone() for k, v in sd0.items()}
-    for v in sd.values():
-        if v.dtype.is_floating_point:
-            v.requires_grad_(True)
     ut = {'user_embedding': model_ref.RefTable('categorical', np.arange(ds.n_users), n_categories=ds.n_users)}
     it = {k: model_ref.table_from_feature(f) for k, f in ds.item_features.items()}
     orders = {'item_train': net.item_embedding_module.train_modality_order, 'item_eval': net.item_embedding_module.eval_modality_order}
-    ref = model_ref.RefSingleBranchNet(sd, C1_MODEL, ut, it, orders=orders)
     rloss = losses_ref.RefRecLoss('bpr', n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole',
                                   neg_train=ds.n_negative_samples)
-    opt = train_ref.make_optimizer('adamw', [p for k, p in sd.items() if p.requires_grad and 'running' not in k], 1e-3, 1e-6)
     inter = ds.user_sampling_matrix
     positives = [inter.indices[inter.indptr[u]:inter.indptr[u + 1]] for u in range(ds.n_users)]
     coo = ds.interaction_matrix
-    rng = np.random.default_rng(0)
-    np.random.seed(42)
-    times, recorded, cpu_losses = [], [], []
-    for s_ in range(C1_TRAIN_STEPS):
-        sel = rng.integers(0, coo.nnz, size=256)
-        t0 = time.perf_counter()
-        u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
-        mods = ref.sides['item'].sample_modalities(i.shape, True)                 # the per-row rng.choice calls of utilities/utils.py:69
-        cpu_losses.append(train_ref.train_step(ref, rloss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), None, mods)['loss'])
-        times.append(time.perf_counter() - t0)
-        recorded.append((u, i, l, mods))
-    cpu_step = sum(times[5:55]) / 50
-    # one CPU evaluation pass on the TRAINED parameters (eval/eval.py:205-222: item representations once, user batches of 256)
     ev = ds.eval_view()
     excl, labels = ev.exclude_data.tocsr(), ev.user_sampling_matrix.tocsr()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        i_repr = ref.item_repr(torch.arange(ds.n_items), False)
-        nd = []
-        for lo in range(0, ds.n_users, 256):
-            ub = torch.arange(lo, min(lo + 256, ds.n_users))
-            r = eval_ref.evaluate(ref.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray(), labels[lo:lo + 256].toarray(), ks=(10,))
-            nd.append(r['ndcg@10'])
-    cpu_eval = time.perf_counter() - t0
-    cpu_ndcg = float(torch.cat(nd).mean())
-    # ---- GPU engine: the same recorded batches and draws from the same initial parameters
-    net.train()
-    gopt = S.FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=1e-6)
-    fused = S.FusedTrainStep(net, bpr, gopt)
+    import re
+    trainable = [k for k, v in sd0.items() if v.dtype.is_floating_point and 'running' not in k]
+    # a Linear bias directly in front of a BatchNorm has a mathematically zero gradient (the BatchNorm subtracts the batch mean): what
+    # either side computes for it is rounding noise, and Adam turns noise into +-lr steps of either sign from the first step on. The
+    # parameter distance is therefore reported with and without those biases.
+    def _shadowed(k_):
+        m = re.match(r'(.*)layers\.linear_(\d+)\.bias$', k_)
+        if not m:
+            return False
+        pre, i_ = m.group(1), int(m.group(2))
+        if f'{pre}layers.batch_norm_{i_}.weight' in sd0:
+            return True
+        m2 = re.match(r'(.*sb_net\.)(\d+)\.$', pre)
+        n_lin = max(int(x) for x in re.findall(re.escape(pre) + r'layers\.linear_(\d+)\.bias', ' '.join(sd0))) if m2 else -1
+        return bool(m2) and i_ == n_lin and f'{m2.group(1)}{int(m2.group(2)) + 1}.running_mean' in sd0
+    solid = [k for k in trainable if not _shadowed(k)]
+
+    def flat(sd, keys=None):
+        return torch.cat([sd[k].detach().double().reshape(-1).cpu() for k in (keys or trainable)])
+
+    solid_ix = torch.cat([torch.full((sd0[k].numel(),), k in solid, dtype=torch.bool) for k in trainable])
+    theta0 = flat(sd0)
+
+    def cpu_run(threads, recorded):
+        """One training of the CPU port from sd0 (records the batches when ``recorded`` is empty) -> (ref, losses, step times, snapshots)"""
+        torch.set_num_threads(threads)
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for v in sd.values():
+            if v.dtype.is_floating_point:
+                v.requires_grad_(True)
+        ref = model_ref.RefSingleBranchNet(sd, C1_MODEL, ut, it, orders=orders)
+        opt = train_ref.make_optimizer('adamw', [p for k, p in sd.items() if p.requires_grad and 'running' not in k], 1e-3, 1e-6)
+        record = not recorded
+        rng = np.random.default_rng(0)
+        np.random.seed(42)
+        times, losses, snaps = [], [], {}
+        for s_ in range(C1_TRAIN_STEPS):
+            t0 = time.perf_counter()
+            if record:
+                sel = rng.integers(0, coo.nnz, size=256)
+                u, i, l = sampling_ref.recbole_collate(coo.row[sel], coo.col[sel], ds.n_negative_samples, ds.items_in_split, positives)
+                mods = ref.sides['item'].sample_modalities(i.shape, True)             # the per-row rng.choice calls of utilities/utils.py:69
+                recorded.append((u, i, l, mods))
+            else:
+                u, i, l, mods = recorded[s_]
+            losses.append(train_ref.train_step(ref, rloss, opt, torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), None, mods)['loss'])
+            times.append(time.perf_counter() - t0)
+            if s_ + 1 in C1_SNAP:
+                snaps[s_ + 1] = flat(sd)
+        return ref, sd, losses, times, snaps
+
+    def cpu_eval(ref):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            i_repr = ref.item_repr(torch.arange(ds.n_items), False)
+            nd = []
+            for lo in range(0, ds.n_users, 256):
+                ub = torch.arange(lo, min(lo + 256, ds.n_users))
+                r = eval_ref.evaluate(ref.user_repr(ub, False), i_repr, excl[lo:lo + 256].toarray(), labels[lo:lo + 256].toarray(), ks=(10,))
+                nd.append(r['ndcg@10'])
+        return float(torch.cat(nd).mean()), time.perf_counter() - t0
+
+    def gpu_eval(scorer):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evaluator = S.FullEvaluator(config=S.evaluation._Cfg(top_k=(10,), metrics=['ndcg'], calculate_std=False), dataset=ev)
+        m = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': ev, 'batch_size': 256})(), evaluator, device, scorer=scorer)
+        torch.cuda.synchronize()
+        return m['ndcg@10'], time.perf_counter() - t0
+
+    # ---- CPU port: C1_CPU_RUNS trainings (the first records every batch and modality draw and is the timed one)
+    recorded, cpu_ndcgs, cpu_threads = [], [], []
+    for r in range(C1_CPU_RUNS):
+        threads = max(1, cores >> r)                        # e.g. 16, 8, 4: different reduction orders, same arithmetic
+        ref, sd, losses, times, snaps = cpu_run(threads, recorded)
+        torch.set_num_threads(cores)
+        nd, ev_s = cpu_eval(ref)
+        cpu_ndcgs.append(nd)
+        cpu_threads.append(threads)
+        if r == 0:
+            cpu_losses, cpu_step, cpu_snaps, cpu_eval_s = losses, sum(times[5:55]) / 50, snaps, ev_s
+            cpu_sd = {k: v.detach().clone() for k, v in sd.items()}
+    # ---- GPU engine: C1_GPU_RUNS trainings on the same recorded batches and draws from the same initial parameters
     order = list(net.item_embedding_module.train_modality_order)
     lut = {m: q for q, m in enumerate(order)}
-    gpu_losses = []
-    for u, i, l, mods in recorded:
-        pos = np.vectorize(lut.__getitem__, otypes=[np.int8])(mods).reshape(-1, mods.shape[-1])
-        gpu_losses.append(fused.step(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), (None, (pos, order)))[0])
-    fused.close()
-    torch.cuda.synchronize()
-    gpu_losses = [float(x) for x in gpu_losses]
-    # the two loss curves: step by step while the trajectories are still the same trajectory (rounding differences grow through the
-    # ReLU gates and the batch statistics: by the end of the run the two models are different samples of the same training run — and so
-    # are two runs of the multi-threaded CPU port, whose reductions are not ordered)
+    pos_of = [np.vectorize(lut.__getitem__, otypes=[np.int8])(mods).reshape(-1, mods.shape[-1]) for (_, _, _, mods) in recorded]
+    gpu_ndcgs, gpu16_ndcgs = [], []
+    for r in range(C1_GPU_RUNS):
+        net.load_state_dict({k: v.to(device) for k, v in sd0.items()})
+        net.train()
+        gopt = S.FusedOptimizer(net, 'adamw', lr=1e-3, weight_decay=1e-6)
+        fused = S.FusedTrainStep(net, bpr, gopt)
+        losses, snaps = [], {}
+        for s_, (u, i, l, mods) in enumerate(recorded):
+            losses.append(fused.step(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(l), (None, (pos_of[s_], order)))[0])
+            if r == 0 and s_ + 1 in C1_SNAP:
+                snaps[s_ + 1] = flat(net.state_dict())
+        fused.close()
+        torch.cuda.synchronize()
+        if r == 0:
+            gpu_losses, gpu_snaps = [float(x) for x in losses], snaps
+        gpu_eval_t = {}
+        for scorer in ('fp32', 'fp16_fused'):
+            for rep in range(2 if r == 0 else 1):             # first run: second pass with resident CSRs and warm kernels is the timed one
+                gpu_eval_t[scorer] = gpu_eval(scorer)
+        gpu_ndcgs.append(gpu_eval_t['fp32'][0])
+        gpu16_ndcgs.append(gpu_eval_t['fp16_fused'][0])
+        if r == 0:
+            gpu_eval_first = dict(gpu_eval_t)
+    # the same parameters on both evaluators: the CPU-trained parameters through the GPU evaluation
+    net.load_state_dict({k: v.to(device) for k, v in cpu_sd.items()})
+    cross, _ = gpu_eval('fp32')
+    mc, sc = _mean_sd(cpu_ndcgs)
+    mg, sg = _mean_sd(gpu_ndcgs)
+    pooled = (((len(cpu_ndcgs) - 1) * sc ** 2 + (len(gpu_ndcgs) - 1) * sg ** 2) / max(len(cpu_ndcgs) + len(gpu_ndcgs) - 2, 1)) ** 0.5
+    within = abs(mg - mc) <= 2.0 * pooled
+    def _rel(k_, ix=None):
+        a, b, z = gpu_snaps[k_], cpu_snaps[k_], theta0
+        if ix is not None:
+            a, b, z = a[ix], b[ix], z[ix]
+        return float(f'{float((a - b).norm() / (b - z).norm().clamp_min(1e-30)):.3g}')
+    dist = {str(k): _rel(k) for k in C1_SNAP}
+    dist_solid = {str(k): _rel(k, solid_ix) for k in C1_SNAP}
     first = max(abs(a - b) / max(abs(a), 1e-12) for a, b in zip(cpu_losses[:20], gpu_losses[:20]))
     tail_cpu, tail_gpu = sum(cpu_losses[-50:]) / 50, sum(gpu_losses[-50:]) / 50
-    gpu_eval = {}
-    for scorer in ('fp32', 'fp16_fused'):
-        for rep in range(2):                                 # second pass: resident CSRs, warm kernels
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            evaluator = S.FullEvaluator(config=S.evaluation._Cfg(top_k=(10,), metrics=['ndcg'], calculate_std=False), dataset=ev)
-            m = S.evaluate_recommender_algorithm(net, type('L', (), {'dataset': ev, 'batch_size': 256})(), evaluator, device, scorer=scorer)
-            torch.cuda.synchronize()
-            gpu_eval[scorer] = (time.perf_counter() - t0, m['ndcg@10'])
-    rel = abs(gpu_eval['fp32'][1] - cpu_ndcg) / max(abs(cpu_ndcg), 1e-12)
-    within = abs(gpu_eval['fp32'][1] - cpu_ndcg) <= 0.01 * abs(cpu_ndcg) + 1e-4
-    if rel > 0.05 and abs(gpu_eval['fp32'][1] - cpu_ndcg) > 5e-4:
-        raise RuntimeError(f'c1: NDCG@10 after {C1_TRAIN_STEPS} identical steps: CPU port {cpu_ndcg:.6f}, GPU engine {gpu_eval["fp32"][1]:.6f}')
-    # ---- GPU training throughput (the trained net keeps training)
+    if abs(cross - cpu_ndcgs[0]) > 1e-5 + 1e-4 * abs(cpu_ndcgs[0]):
+        raise RuntimeError(f'c1: the CPU-trained parameters give NDCG@10 {cpu_ndcgs[0]:.6f} on the CPU evaluator and {cross:.6f} on the GPU evaluator')
+    if abs(mg - mc) > 0.05 * abs(mc) and abs(mg - mc) > 5e-4 and not within:
+        raise RuntimeError(f'c1: NDCG@10 after {C1_TRAIN_STEPS} identical steps: CPU port {cpu_ndcgs}, GPU engine {gpu_ndcgs}')
+    # ---- GPU training throughput (from the initial parameters again)
+    net.load_state_dict({k: v.to(device) for k, v in sd0.items()})
     gpu = {}
     for B in (256, 4096):
         n_steps = max(steps, 50)
@@ -644,32 +749,24 @@ def bench_c1(S, device, steps):
     out.update({
         'gpu': gpu,
         'cpu': {'value': round(256 / cpu_step, 1), 'unit': 'interactions/s', 'ms_per_step': round(cpu_step * 1e3, 2), 'batch': 256,
-                'timed_steps': 50, 'warmup_steps': 5, 'cores': cores, 'kind': 'port',
-                'what': f'oracle restatement of the reference step (torch {torch.__version__} CPU fp32, per-row numpy modality draws, '
-                        f'literal collate loop), same data and initial parameters'},
+                'timed_steps': 50, 'warmup_steps': 5, 'cores': cores, 'kind': 'port'},
         'speedup_vs_cpu': {'b256': round(gpu['b256']['value'] / (256 / cpu_step), 1),
                            'b4096_vs_cpu_b256': round(gpu['b4096']['value'] / (256 / cpu_step), 1)},
-        'trained_ndcg': {'what': f'NDCG@10 (one held-out item per user, train exclusions) after the SAME {C1_TRAIN_STEPS} recorded batches '
-                                 f'(batch 256, literal collate + per-row modality draws) from the same initial parameters on both sides',
-                         'cpu_port': round(cpu_ndcg, 6), 'gpu_fp32_scorer': round(gpu_eval['fp32'][1], 6),
-                         'gpu_fp16_fused_scorer': round(gpu_eval['fp16_fused'][1], 6), 'rel_diff_fp32_vs_cpu': round(rel, 5),
-                         'within_1pct_plus_1e-4': bool(within),
-                         'note': 'both trainings are samples of one training run (unordered multi-threaded reductions on the CPU, float atomics on the '
-                                 'GPU: each side moves by ~1 % from run to run, the difference between them between 0.1 and 2 %); the same '
-                                 'parameters give the same NDCG@10 on both evaluators to six digits (tools/lab/c1_cross_eval.py); loss_curves '
-                                 'compares the trainings step by step'},
-        'loss_curves': {'what': 'total loss of the same recorded steps on both sides', 'max_rel_diff_first_20_steps': float(f'{first:.3g}'),
-                        'mean_last_50_steps_cpu': round(tail_cpu, 6), 'mean_last_50_steps_gpu': round(tail_gpu, 6),
-                        'rel_diff_last_50': float(f'{abs(tail_cpu - tail_gpu) / max(abs(tail_cpu), 1e-12):.3g}')},
-        'eval': {'scores': n_scores,
-                 'cpu': {'value': round(n_scores / cpu_eval, 1), 'unit': 'scores/s', 'seconds': round(cpu_eval, 3), 'cores': cores,
-                         'ndcg@10': round(cpu_ndcg, 6)},
-                 'gpu_fp32': {'value': round(n_scores / gpu_eval['fp32'][0], 1), 'unit': 'scores/s',
-                              'seconds': round(gpu_eval['fp32'][0], 5), 'ndcg@10': round(gpu_eval['fp32'][1], 6)},
-                 'gpu_fp16_fused': {'value': round(n_scores / gpu_eval['fp16_fused'][0], 1), 'unit': 'scores/s',
-                                    'seconds': round(gpu_eval['fp16_fused'][0], 5), 'ndcg@10': round(gpu_eval['fp16_fused'][1], 6)},
-                 'what': 'one full evaluation pass of the TRAINED parameters: item representations, all users, train exclusions, '
-                         'top-10, NDCG@10 (one held-out item per user)'}})
+        'trained_ndcg': {'what': f'NDCG@10 after the SAME {C1_TRAIN_STEPS} recorded batches of 256 from the same initial parameters: '
+                                 f'{C1_GPU_RUNS} GPU trainings, {C1_CPU_RUNS} CPU-port trainings (threads {cpu_threads})',
+                         'cpu_runs': [round(x, 6) for x in cpu_ndcgs], 'gpu_runs_fp32_scorer': [round(x, 6) for x in gpu_ndcgs],
+                         'gpu_runs_fp16_fused_scorer': [round(x, 6) for x in gpu16_ndcgs],
+                         'cpu_mean': round(mc, 6), 'cpu_sd': float(f'{sc:.3g}'), 'gpu_mean': round(mg, 6), 'gpu_sd': float(f'{sg:.3g}'),
+                         'abs_diff_of_means': float(f'{abs(mg - mc):.3g}'), 'pooled_sd': float(f'{pooled:.3g}'), 'within_spread': bool(within),
+                         'criterion': '|mean_gpu - mean_cpu| <= 2 pooled sd',
+                         'same_parameters_both_evaluators': {'cpu_params_cpu_eval': round(cpu_ndcgs[0], 6), 'cpu_params_gpu_eval': round(cross, 6)},
+                         'param_distance_gpu_vs_cpu_over_cpu_travel': dist,
+                         'param_distance_without_biases_in_front_of_a_batchnorm': dist_solid},
+        'loss_curves': {'max_rel_diff_first_20_steps': float(f'{first:.3g}'),
+                        'rel_diff_mean_last_50': float(f'{abs(tail_cpu - tail_gpu) / max(abs(tail_cpu), 1e-12):.3g}')},
+        'eval': {'scores': n_scores, 'cpu_scores_per_s': round(n_scores / cpu_eval_s, 1), 'cpu_cores': cores,
+                 'gpu_fp32_scores_per_s': round(n_scores / gpu_eval_first['fp32'][1], 1),
+                 'gpu_fp16_fused_scores_per_s': round(n_scores / gpu_eval_first['fp16_fused'][1], 1)}})
     return out
 
 
@@ -700,10 +797,10 @@ def bench_c3(S, device, steps):
         if B == 4096 and timings:
             roof = dominant_gemm(timings, n_steps, None)
             if roof:
-                roof['all_gemms'] = gemm_table(timings, n_steps)[:12]
+                TABLES['c3_b4096_all_gemms'] = gemm_table(timings, n_steps)
+                TABLES['c3_b4096_all_kernels'] = kernel_table(timings, n_steps)
                 gemm_ms = sum(r['ms_per_step'] for r in gemm_table(timings, n_steps))
                 roof['gemm_ms_per_step'] = round(gemm_ms, 4)
-                roof['all_kernels'] = kernel_table(timings, n_steps)[:24]
                 out['roofline'] = roof
     return out
 
@@ -735,6 +832,111 @@ def cpu_scoring_sample(S, ds, net, n_users=2048, k=20):
     return {'value': round(ds.n_users * ds.n_items / full, 1), 'unit': 'scores/s', 'cores': cores, 'kind': 'port',
             'sample': f'item representations of all {ds.n_items} items ({t_items:.2f} s) + {n_users} of {ds.n_users} users in batches of '
                       f'256 ({t_users:.2f} s: scores, exclusion mask, top-{k}), extrapolated to the full pass'}
+
+
+def replica_checksum(net, device):
+    """Data-parallel sanity: after identical initialisation and exchanged gradients every replica must hold the same trainable
+    parameters (BatchNorm running statistics are rank-local by design and are not parameters) -> (relative spread, checksums)"""
+    import torch.distributed as dist
+    with torch.no_grad():
+        chk = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in net.parameters()]).sum(),
+                           torch.cat([p.detach().double().abs().reshape(-1) for p in net.parameters()]).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max()), [float(c) for c in chk]
+
+
+C4 = dict(n_users=1_000_000, n_items=200_000, nnz=4_000_000, n_neg=10)
+C4_MODEL = {'shared_common_dim': 256, 'user': {'feature_name': 'user_embedding', 'embedding_dim': -1},
+            'item': {'features': [{'feature_name': 'text'}, {'feature_name': 'image'}], 'single_branch_hidden_layers': [256],
+                     'preference_hidden_layers': [], 'common_modality_dim': 256}}
+
+
+def bench_c4_dp(S, device, rank, world, steps, small=False):
+    """BASELINE configs[3] at its own size in the data-parallel job (world > 1): AmazonVideo2024-shaped synthetic data, 1M users x 200k
+    items, text 768-d + image 2048-d, C = D = 256, user = embedding lookup (1 GB table per replica), sampled softmax, AdamW; every rank
+    trains its own batch of 256 / 8192 interactions per step (weak scaling), the lookup table's gradient goes through the sparse
+    (row, gradient) all-gather, everything else through the flat all-reduce."""
+    c = dict(C4)
+    if small:
+        c.update(n_users=50_000, n_items=10_000, nnz=300_000)
+    ds = S.SyntheticDataset(c['n_users'], c['n_items'], c['nnz'], item_dense={'text': 768, 'image': 2048}, seed=0,
+                            n_negative_samples=c['n_neg'], negative_sampling_strategy='uniform_recbole', holdout_per_user=0)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    net = S.SingleBranchNet(S.SingleBranchNetConfig.from_dict(C4_MODEL), ds).to(device)
+    out = {'workload': f'BASELINE configs[3]: {c["n_users"]} users x {c["n_items"]} items, text 768 + image 2048, C = D = 256, user = lookup, '
+                       f'sampled softmax, AdamW, dp{world}' + (' [SMALL DEBUG SIZE]' if small else ''),
+           'params': sum(p.numel() for p in net.parameters())}
+    n_steps = max(min(steps, 50), 10)
+    for B in (256, 8192):
+        dt, _ = bench_training(S, ds, net, device, B, n_steps, 5, rank, world, time_kernels=False)
+        out[f'b{B}'] = {'value': round(B * world * n_steps / dt, 1), 'unit': 'interactions/s', 'ms_per_step': round(dt / n_steps * 1e3, 3),
+                        'batch_per_gpu': B, 'steps': n_steps, 'user_table_gradient_exchange': EXCHANGE.get(B),
+                        'loss_after_timed_steps': LAST_LOSS.get(B)}
+    spread, chk = replica_checksum(net, device)
+    out['replica_param_checksum_spread'] = spread
+    out['param_checksum'] = chk
+    return out
+
+
+def bench_c5_dist(S, device, rank, world, small=False, k=20, chunk=100_000):
+    """BASELINE configs[4] at its own size in the item-sharded job (world > 1): 1M users x 200k items x 256 fp16 N(0, 1)/16
+    representations, 50 excluded items per user, top-20. Rank r holds items [lo_r, hi_r) and scores every 100k-user chunk against them
+    with the fused kernel (item_offset = lo_r), the [chunk, k] lists are all-gathered and merged exactly (parallel.all_gather_topk ->
+    sbr_merge_topk). One timed pass over all users with every chunk's exclusion mask resident (eval/eval.py:219: constant per split)."""
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    U, I, D = (1_000_000, 200_000, 256) if not small else (60_000, 20_000, 256)
+    chunk = chunk if not small else 20_000
+    lo, hi = S.parallel.item_shard(I, rank, world)
+    g = torch.Generator(device='cpu').manual_seed(5)                      # the same tensors on every rank
+    i_all = (torch.randn(I, D, generator=g) / 16).half()
+    i16 = i_all[lo:hi].contiguous().to(device)
+    del i_all
+    chunks = []
+    rng = np.random.default_rng(5)
+    for s in range(0, U, chunk):
+        n = min(chunk, U - s)
+        u16 = (torch.randn(n, D, generator=g) / 16).half().to(device)
+        cols = np.sort(rng.integers(0, I, size=(n, 50)), axis=1)
+        m = sp.csr_matrix((np.ones(n * 50, dtype=np.int8), cols.reshape(-1), np.arange(0, n * 50 + 1, 50)), shape=(n, I))
+        m.sum_duplicates()
+        chunks.append((u16, torch.arange(n, device=device), S.evaluation._csr_to_device(m, device), S.ops.ScorerExclusions()))
+
+    def one_pass():
+        last = None
+        for u16, users, excl, holder in chunks:
+            val, idx = S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo, exclusions=holder)
+            last = S.parallel.all_gather_topk(val, idx, k)
+        return last
+
+    with torch.no_grad():
+        one_pass()                                                         # builds the resident masks, warms the kernels
+        one_pass()
+        S.ops.KernelTimer.reset(True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        val, idx = one_pass()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        ts = [t for key, v in S.ops.KernelTimer.results().items() if key[0] == 'score_topk_f16' for t in v]
+        S.ops.KernelTimer.reset(False)
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    ok = bool((idx[:, 0] >= 0).all()) and bool((idx.max() < I)) and bool((val[:, :-1] >= val[:, 1:]).all())
+    avg_ms = sum(ts) / len(ts)
+    return {'workload': f'BASELINE configs[4]: {U} users (chunks of {chunk}) x {I} items x {D} fp16, item-sharded over {world} ranks '
+                        f'({hi - lo} items on this rank), 50 exclusions per user, top-{k}, all-gather + exact merge of the lists'
+                        + (' [SMALL DEBUG SIZE]' if small else ''),
+            'value': round(U * I / dt, 1), 'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'chunks': len(chunks),
+            'sharding': f'items/{world}', 'lists_sorted_and_in_range': ok,
+            'roofline': scoring_roofline(chunks[0][0].shape[0], hi - lo, D, k, avg_ms,
+                                         kernel='fused fp16 scorer on this rank\'s item shard, one 100k-user chunk (rank 0\'s launches)')}
 
 
 def launch_ranks(n: int) -> int:
@@ -854,44 +1056,72 @@ def main():
                    'loss_after_timed_steps': LAST_LOSS.get(args.batch_size)},
     }
     if world > 1:
-        # data-parallel sanity: after identical initialisation and all-reduced gradients every replica must hold the same
-        # trainable parameters (BatchNorm running statistics are rank-local by design and are not parameters)
-        with torch.no_grad():
-            chk = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in net.parameters()]).sum(),
-                               torch.cat([p.detach().double().abs().reshape(-1) for p in net.parameters()]).sum()])
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            out['config']['replica_param_checksum_spread'] = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
-            out['config']['param_checksum'] = [float(c) for c in chk]
-            out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
+        spread, chk = replica_checksum(net, device)
+        out['config']['replica_param_checksum_spread'] = spread
+        out['config']['param_checksum'] = chk
+        out['config']['user_table_gradient_exchange'] = EXCHANGE.get(args.batch_size)
     n_params = sum(p.numel() for p in net.parameters())
     utab = net.user_embedding_module.embedding_layer.weight
     roof = step_roofline(timings, args.steps, args.batch_size, n_params, utab.numel(), utab.shape[1]) if rank == 0 else None
     if roof:
-        out['roofline'] = roof
+        out['roofline'] = compact_roofline(roof)
+    b256 = sc = c5 = c3 = c1 = None
     if not args.no_b256:
         dt256, _ = bench_training(S, ds, net, device, 256, max(args.steps, 30), args.warmup, rank, world, time_kernels=False)
-        out['b256'] = {'value': round(256 * world * max(args.steps, 30) / dt256, 1), 'unit': 'interactions/s',
-                       'ms_per_step': round(dt256 / max(args.steps, 30) * 1e3, 3), 'batch_per_gpu': 256}
+        b256 = {'value': round(256 * world * max(args.steps, 30) / dt256, 1), 'unit': 'interactions/s',
+                'ms_per_step': round(dt256 / max(args.steps, 30) * 1e3, 3), 'batch_per_gpu': 256}
     if not args.no_scoring:
         sc = bench_scoring(S, ds, net, device, rank, world)
         sc['value'] = round(sc['value'], 1)
-        out['scoring'] = sc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(S, ds, net, args.batch_size)
-        out['cpu_baseline']['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 1)
-        if 'scoring' in out:
-            out['scoring']['cpu_baseline'] = cpu_scoring_sample(S, ds, net)
-            out['scoring']['cpu_baseline']['speedup_vs_cpu'] = round(out['scoring']['value'] / out['scoring']['cpu_baseline']['value'], 1)
+        cb = cpu_baseline(S, ds, net, args.batch_size)
+        TABLES['cpu_baseline_step_seconds'] = cb.pop('step_seconds')
+        cb['speedup_vs_cpu'] = round(value / cb['value'], 1)
+        out['cpu_baseline'] = cb
+        if sc is not None:
+            sc['cpu_baseline'] = cpu_scoring_sample(S, ds, net)
+            sc['cpu_baseline']['speedup_vs_cpu'] = round(sc['value'] / sc['cpu_baseline']['value'], 1)
     if rank == 0 and world == 1 and not args.no_configs and not args.small:
         del ds, net
-        out['c5_shard'] = bench_c5_shard(S, device)
-        out['c3'] = bench_c3(S, device, args.steps)
+        c5 = bench_c5_shard(S, device)
+        c3 = bench_c3(S, device, args.steps)
+        if 'roofline' in c3:
+            c3['roofline'] = compact_roofline(c3['roofline'])
     if rank == 0 and world == 1 and not args.no_c1 and not args.small:
-        out['c1'] = bench_c1(S, device, args.steps)
+        c1 = bench_c1(S, device, args.steps)
+    c4dp = c5d = None
+    if world > 1 and not args.no_configs:
+        # the two BASELINE configs that name 8 GPUs, at their own sizes, next to the c2 curve (every rank takes part)
+        del ds, net
+        torch.cuda.empty_cache()
+        c5d = bench_c5_dist(S, device, rank, world, small=args.small)
+        c4dp = bench_c4_dp(S, device, rank, world, args.steps, small=args.small)
     if rank == 0:
-        print(json.dumps(out))
+        # the metric's second half (scores/s) also rides inside the two objects every record keeps, and the compact objects of the other
+        # measurements come LAST so that a tail of the line always shows them; the per-kernel tables go to a side file
+        if sc is not None and 'roofline' in out:
+            out['roofline']['scoring_gemm'] = {k: sc['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')}
+            out['roofline']['scoring_gemm']['scores_per_s'] = sc['value']
+        if sc is not None and 'cpu_baseline' in out and 'cpu_baseline' in sc:
+            out['cpu_baseline']['scoring'] = {k: sc['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'speedup_vs_cpu')}
+        for key, obj in (('c1', c1), ('c3', c3), ('c4_dp', c4dp), ('c5', c5d), ('b256', b256), ('c5_shard', c5), ('scoring', sc)):
+            if obj is not None:
+                out[key] = obj
+        out['tables'] = write_tables()
+        line = json.dumps(out)
+        if len(line) > 7600:                                  # the record keeps an 8 KB tail: shed prose before numbers
+            for path in (('c1', 'workload'), ('c3', 'workload'), ('c1', 'trained_ndcg', 'what'), ('scoring', 'exclusion_mask'),
+                         ('roofline', 'traffic_source'), ('roofline', 'timing'), ('c5_shard', 'workload'), ('scoring', 'cpu_baseline', 'sample'),
+                         ('cpu_baseline', 'sample'), ('roofline', 'dominant_gemm')):
+                o = out
+                for k_ in path[:-1]:
+                    o = o.get(k_, {}) if isinstance(o, dict) else {}
+                if isinstance(o, dict):
+                    o.pop(path[-1], None)
+                line = json.dumps(out)
+                if len(line) <= 7600:
+                    break
+        print(line)
     if dist.is_initialized():
         dist.destroy_process_group()
 

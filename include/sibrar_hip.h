@@ -422,6 +422,12 @@ int sbr_score_topk_f16(const void* U_f16, const void* I_f16, int D, long Bu, int
  * and read by the final-selection launch of the same call; contents need no initialisation) + their fill counts. */
 long sbr_score_topk_f16_workspace(long Bu, int I, int k);
 long sbr_score_topk_f16_events_bytes(long Bu, long excl_nnz);
+/* ABI 4: which of the two fused scorers sbr_score_topk_f16 runs. 0 (default): the two-pass scorer (csrc/score_topk_f16_2p.hip: a pure
+ * MFMA + group-maxima pass, then the ~3 % of the scores at or above each user's bound are recomputed group by group) for catalogues of
+ * >= 8,192 items, the one-pass kernel (csrc/score_topk_f16_n.hip) below; 1: always one-pass; 2: two-pass or an error. Both return the same
+ * lists bit for bit (same MFMA chain per score); the switch exists for tests and A/B timing. Returns the previous setting; a value
+ * outside 0..2 only queries. Process-wide. */
+int sbr_score_topk_f16_route(int route);
 /* fp32 -> fp16 cast of an embedding matrix (row-major, contiguous) */
 int sbr_cast_f32_to_f16(const float* X, void* Y_f16, long n, void* stream);
 

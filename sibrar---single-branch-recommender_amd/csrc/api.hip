@@ -12,4 +12,4 @@ void sbr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sbr_last_error(void) { return g_err; }
-extern "C" int sbr_abi_version(void) { return 3; }
+extern "C" int sbr_abi_version(void) { return 4; }

@@ -783,6 +783,13 @@ class ScorerExclusions:
         self.buf, self.key = None, None
 
 
+def score_topk_route(route: int = -1) -> int:
+    """Which fused scorer ``score_topk_f16`` runs (process-wide; returns the previous setting): 0 automatic — the two-pass scorer
+    (csrc/score_topk_f16_2p.hip) for catalogues of >= 8,192 items, the one-pass kernel below —, 1 always one-pass, 2 two-pass or an
+    error; -1 only queries. Both return the same lists bit for bit; the switch exists for tests and A/B timing."""
+    return int(lib().sbr_score_topk_f16_route(int(route)))
+
+
 def score_topk_f16(u16: torch.Tensor, i16: torch.Tensor, k: int, u_idx=None, excl_indptr=None, excl_indices=None,
                    item_offset: int = 0, exclusions: 'ScorerExclusions' = None):
     _need_cuda(u16, i16)

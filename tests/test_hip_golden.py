@@ -595,7 +595,7 @@ def test_two_rank_data_parallel_rehearsal_on_one_gpu():
     env['SBR_DIST_BACKEND'] = 'gloo'
     # no external launcher: `bench.py --gpus 2` starts its two ranks itself (bench.launch_ranks)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '20', '--warmup', '3', '--no-b256']
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1]
     out = json.loads(line)
@@ -605,6 +605,15 @@ def test_two_rank_data_parallel_rehearsal_on_one_gpu():
     assert 'all-gather' in out['config']['user_table_gradient_exchange']
     assert 0.0 < out['config']['loss_after_timed_steps'] < 2.45          # ln(11) = 2.40 at initialisation, falling
     assert out['scoring']['sharding'] == 'items/2' and out['scoring']['value'] > 0
+    # the two BASELINE configs that name 8 GPUs ride in the multi-GPU line at their own shapes (reduced user / item counts under --small):
+    # c4 data-parallel with the sparse row exchange, c5 item-sharded with the top-k all-gather + merge
+    c4, c5 = out['c4_dp'], out['c5']
+    assert c4['replica_param_checksum_spread'] == 0.0
+    for b in ('b256', 'b8192'):
+        assert 'all-gather' in c4[b]['user_table_gradient_exchange'] and c4[b]['value'] > 0
+        assert 0.0 < c4[b]['loss_after_timed_steps'] < 2.45
+    assert c5['sharding'] == 'items/2' and c5['lists_sorted_and_in_range'] and c5['value'] > 0 and c5['chunks'] == 3
+    assert len(line) < 8000, f'the bench line is {len(line)} bytes: the record keeps an 8 KB tail'
 
 
 @pytest.mark.gpu

@@ -28,8 +28,25 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r' T (sbr_\w+)', out))
     assert set(protos) <= exported, set(protos) - exported
     assert exported <= set(protos), f'exported but undeclared: {exported - set(protos)}'
-    assert handle.sbr_abi_version() == 3
+    assert handle.sbr_abi_version() == 4
     assert handle.sbr_last_error() is not None
+
+
+def test_product_library_carries_no_lab_switches():
+    """The timing-only ablations of the fused scorer (wrong results by design) and the environment switches that selected them are
+    compiled only into lab builds (-DSBR_LAB, tools/lab/build_scorer_variants.sh): the product library holds ONE instantiation of the
+    scorer kernel per supported D and never mentions the variables."""
+    from importlib import import_module
+    _lib = import_module('sibrar---single-branch-recommender_amd._lib')
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run(['nm', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    kernels = set(re.findall(r' [VW] (_Z\d+score_topk_f16_n_kernelI\w+)', out))
+    assert len(kernels) == 3, kernels                                   # D = 64, 128, 256
+    assert all(re.search(r'ELi0ELb[01]EEv', k) for k in kernels), kernels     # template argument DBG = 0
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'SBR_ST_DEBUG' not in blob and b'SBR_ST_PRE' not in blob
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
