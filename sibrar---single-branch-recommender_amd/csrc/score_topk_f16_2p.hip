@@ -15,32 +15,33 @@
 //                                   stored (M: 8 bytes per lane and supertile); each also feeds one of 16 threshold classes per lane
 //                                   (32 per user), and at the end of the pass L = the k-th largest of the user's 32 class maxima: k
 //                                   groups of different classes hold an item with score >= L, so the k-th best score is >= L.
-//   select  score_select_kernel     per block of 512 users: every group with M >= L is a (user, group) PAIR (~31 per user); the pairs
-//                                   of the block are counting-sorted by group in LDS (two sweeps over M: count, scan, scatter).
+//   select  score_select_kernel     one wave per 32-user unit, one sweep over M: every group with M >= L is a (user, group) PAIR (~31 per
+//                                   user). A ballot over the unit's lanes IS the pair set of a group: one 32-bit word per (group, unit),
+//                                   bit = user — a bitmap of G x units words (10 MB for 100k users x 50k items), every word written once.
 //   pass 2  score_rescore_kernel    one workgroup per (superblock of 8,192 / 4,096 users, group): the group's 64 item rows in LDS, the
-//                                   pairs' user rows gathered 32 at a time as the B operand, the SAME MFMA chain as pass 1 (same
-//                                   instruction, operand roles and k order: every score comes out bit-identical), scores >= L are
-//                                   appended to the pair's 64-byte candidate region (3 entries per lane half + a count; more go to a
-//                                   per-user overflow list). Work items are ordered superblock-major so that the user rows a
+//                                   superblock's row of the bitmap expanded into the user list, the users' rows gathered 32 at a time as
+//                                   the B operand, the SAME MFMA chain as pass 1 (same instruction, operand roles and k order: every
+//                                   score comes out bit-identical); scores >= L are appended to the user's candidate list (one atomic
+//                                   add per lane reserves its entries). Work items are ordered superblock-major so that the user rows a
 //                                   superblock touches (2 MB) stay in the XCDs' L2 while its ~31 pairs per user are served.
-//   final   score_finalize2_kernel  one wave per user: candidates of its pairs, exclusion filter (binary search in the user's CSR row:
-//                                   pass 2 does not see exclusions), exact ranking by (score desc, item asc).
+//   final   score_finalize2_kernel  one wave per user: its candidate list (~45 entries, one coalesced load), exclusion filter (the
+//                                   user's sorted CSR row in LDS: pass 2 does not see exclusions), exact ranking (score desc, item asc).
 //
 // Exactness. Every non-excluded item with score >= L lies in a group whose (masked) maximum is >= L, hence in a selected pair, hence
-// among the candidates; at least k such items exist; so the k best of the candidates are the k best of the catalogue. Users for whom
-// the bookkeeping does not fit (more than S2_JMAX groups at or above L — massive ties —, overflowing overflow lists, fewer than k
-// scoreable items) are HARD: their wave of the final kernel streams the whole catalogue itself with the same MFMA chain (slow, exact).
+// among the candidates; at least k such items exist; so the k best of the candidates are the k best of the catalogue. Users whose
+// candidate list overflows (massive ties: every group ties at the bound) or who have fewer than k scoreable items are HARD: their wave
+// of the final kernel streams the whole catalogue itself with the same MFMA chain (slow, exact).
 #include "score_topk_shared.h"
 
 #define S2_SUPER 512                     // items per supertile
-#define S2_JMAX 96                       // pairs per user
-#define S2_BU 16                         // units (32 users) per selection block
-#define S2_BLOCK_USERS (32 * S2_BU)
-#define S2_PAIRCAP (S2_BLOCK_USERS * S2_JMAX)      // pair slots of a selection block
-#define S2_OVF_CAP 64                    // overflow candidates per user
+#define S2_CAND_CAP 128                  // candidate entries per user (typical: ~45)
 #define S2_MIN_ITEMS 8192                // below: the one-pass kernel (all 32 threshold classes need groups)
-#define S2_MAX_GROUPS 16000              // LDS histogram of the selection kernel
-#define S2_STAGE 256                     // candidates a wave of the final kernel can stage
+#define S2_STAGE 256                     // candidates a wave of the final kernel can stage (the hard path compacts beyond)
+#define S2_CHUNK 512                     // pairs of a work item staged in LDS at a time
+#ifndef S2_ABL
+#define S2_ABL 0                         // lab builds only (timing, wrong results): 1 = no atomics in pass 2's flush, 2 = no flush, 3 = no user-row gather, 4 = no epilogue, 5 = no epilogue and no MFMA, 6 = set-up only
+#endif
+#define S2_ROWCAP 256                    // exclusion-row entries a wave keeps in LDS (longer rows: binary search in memory)
 
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ float s2_max3(float a, float b, float c) {
 template <int KS, int NS, int NJ>
 __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I,
                                                              const unsigned int* __restrict__ events, const int* __restrict__ group_base, int k, int W,
-                                                             int n_part, int P, uint2* __restrict__ M, float* __restrict__ Lbuf) {
+                                                             int n_part, int P, uint4* __restrict__ M, float* __restrict__ Lbuf) {
   constexpr int D = KS * 16;
   constexpr int ST_TILE = 32 * NJ;
   constexpr int X = S2_SUPER / ST_TILE;                    // tiles per supertile
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  // units as in the one-pass kernel: W full consumer waves per workgroup; remainder units are cut into P parts — here by SUPERTILE
-  // (supertile st belongs to part st % P), so that every group maximum is produced whole by one wave
+  // units as in the one-pass kernel: W full consumer waves per workgroup; remainder units are cut into P parts — here by supertile
+  // PAIR (supertiles 2q, 2q + 1 belong to part q % P), so that every 16-byte row of M is produced whole by one wave
   const int Wb = W + ((int)blockIdx.x < n_part ? 1 : 0);
   const bool partial = wave == W && (int)blockIdx.x < n_part;
   const int part = partial ? (int)blockIdx.x % P : 0, n_parts = partial ? P : 1;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
   const long n_units = (Bu + 31) >> 5;
   const int n_tiles = (I + ST_TILE - 1) / ST_TILE;
   const int n_st = (n_tiles + X - 1) / X;
+  const int n_st2 = (n_st + 1) >> 1;                       // 16-byte rows of M per lane: two supertiles each
 
   if (t < NS) { full_lds[t] = 0; free_lds[t] = 0; }
   __syncthreads();
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
   for (int c = 0; c < 4; ++c) cm[c] = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) *(__attribute__((address_space(3))) float*)(size_t)(tc_addr + r * 256) = -INFINITY;
-  uint2* mrow = M + (unit * n_st) * 64 + lane;             // this lane's slot of supertile 0 (a unit's rows are contiguous)
+  uint4* mrow = M + (unit * n_st2) * 64 + lane;            // this lane's slot of supertile pair 0 (a unit's rows are contiguous)
+  unsigned int pk0 = 0xFF80FF80u, pk1 = 0xFF80FF80u;       // the even supertile's packed maxima, kept until the odd one is done (-inf)
 
   int st = 0, tin = 0;                                      // supertile of the tile, tile inside the supertile
   int st_part = 0;                                          // st % n_parts
@@ -284,10 +287,15 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
       if (mine) {
         // the supertile's four group maxima of this lane: rounded down to bf16, stored, and fed to the threshold classes
         const unsigned int f0 = s2_floor_bf16(cm[0]), f1 = s2_floor_bf16(cm[1]), f2 = s2_floor_bf16(cm[2]), f3 = s2_floor_bf16(cm[3]);
-        uint2 o;
-        o.x = (f0 >> 16) | f1;
-        o.y = (f2 >> 16) | f3;
-        mrow[(long)st * 64] = o;
+        const unsigned int q0 = (f0 >> 16) | f1, q1 = (f2 >> 16) | f3;
+        if ((st & 1) == 0 && st + 1 < n_st) {
+          pk0 = q0; pk1 = q1;
+        } else {
+          uint4 o;
+          if (st & 1) { o.x = pk0; o.y = pk1; o.z = q0; o.w = q1; }
+          else { o.x = q0; o.y = q1; o.z = 0xFF80FF80u; o.w = 0xFF80FF80u; }      // the last supertile has no partner
+          mrow[(long)(st >> 1) * 64] = o;
+        }
         const unsigned int a = tc_addr + (unsigned int)((st & 3) * 1024);
         asm volatile("ds_max_f32 %0, %1\n\tds_max_f32 %0, %2 offset:256\n\tds_max_f32 %0, %3 offset:512\n\tds_max_f32 %0, %4 offset:768"
                      ::"v"(a), "v"(__uint_as_float(f0)), "v"(__uint_as_float(f1)), "v"(__uint_as_float(f2)), "v"(__uint_as_float(f3)) : "memory");
@@ -295,8 +303,8 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
         for (int c = 0; c < 4; ++c) cm[c] = -INFINITY;
       }
       tin = 0;
+      if (st & 1) st_part = st_part + 1 == n_parts ? 0 : st_part + 1;
       ++st;
-      st_part = st_part + 1 == n_parts ? 0 : st_part + 1;
     } else {
       ++tin;
     }
@@ -316,41 +324,42 @@ __global__ __launch_bounds__(1024) void score_max_f16_kernel(const _Float16* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// selection: (user, group) pairs with M >= L, counting-sorted by group per block of S2_BLOCK_USERS users
+// selection: the (user, group) pairs with M >= L as a bitmap — one 32-bit word per (group, unit), bit = user of the unit
 // ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void s2_unpack(uint2 v, float (&f)[4]) {
+__device__ __forceinline__ void s2_unpack8(uint4 v, float (&f)[8]) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xFFFF0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xFFFF0000u);
 }
 
-__global__ __launch_bounds__(1024) void score_select_kernel(const uint2* __restrict__ M, const float* __restrict__ Lbuf, long n_units, long n_full_units,
-                                                            int n_st, long Bu, int k, int* __restrict__ nsel, int* __restrict__ hard,
-                                                            int* __restrict__ ovf_cnt, int* __restrict__ pair_of, int* __restrict__ offs,
-                                                            int* __restrict__ pairs, float* __restrict__ Lout) {
-  extern __shared__ int hist[];                              // [G + 1]
-  __shared__ int part[1024];
-  const int G = n_st * 8;
-  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const long unit = (long)blockIdx.x * S2_BU + wave;
-  const bool valid = unit < n_units;                         // wave-uniform
+__global__ __launch_bounds__(256) void score_select_kernel(const uint4* __restrict__ M, const float* __restrict__ Lbuf, long n_units, int G,
+                                                           long n_full_units, int n_st, long Bu, int k, const long* __restrict__ u_idx,
+                                                           const long* __restrict__ indptr, unsigned int* __restrict__ bitmap,
+                                                           float* __restrict__ Lout, int* __restrict__ cnt, int* __restrict__ hard,
+                                                           long* __restrict__ row_lo, int* __restrict__ row_len) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long unit = (long)blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;                               // wave-uniform
+  const int n_st2 = (n_st + 1) >> 1;
   const long user = unit * 32 + l31;
-  const bool uvalid = valid && user < Bu;
-  const uint2* mrow = M + (unit * n_st) * 64 + lane;
+  const bool uvalid = user < Bu;
+  const uint4* mrow = M + (unit * n_st2) * 64 + lane;
   float L = INFINITY;
-  if (valid && unit >= n_full_units) {
-    // remainder unit (scored by part waves): the bound from M itself, same threshold classes as pass 1
+  if (unit >= n_full_units) {
+    // remainder unit (scored by part waves, none of which saw the whole catalogue): the bound from M itself, same threshold classes
     float tc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) tc[r] = -INFINITY;
-    for (int s4 = 0; s4 < n_st; s4 += 4) {
+    for (int s2 = 0; s2 < n_st2; s2 += 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (s4 + q < n_st) {
-          float f[4];
-          s2_unpack(mrow[(long)(s4 + q) * 64], f);
+      for (int q = 0; q < 2; ++q) {
+        if (s2 + q < n_st2) {
+          float f[8];
+          s2_unpack8(mrow[(long)(s2 + q) * 64], f);           // supertiles 2 (s2 + q), + 1: threshold slots ((st & 3) * 4 + c)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) tc[q * 4 + c] = fmaxf(tc[q * 4 + c], f[c]);
+          for (int e = 0; e < 8; ++e) tc[q * 8 + e] = fmaxf(tc[q * 8 + e], f[e]);
         }
       }
     }
@@ -359,160 +368,91 @@ __global__ __launch_bounds__(1024) void score_select_kernel(const uint2* __restr
     L = Lbuf[user];
   }
   if (!uvalid) L = INFINITY;
-  for (int i = t; i <= G; i += 1024) hist[i] = 0;
-  __syncthreads();
-  // ---- sweep A: count (eight supertiles' loads in flight per lane)
-  int n = 0;
-  if (valid) {
-    for (int s8 = 0; s8 < n_st; s8 += 8) {
-      uint2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = s8 + q < n_st ? mrow[(long)(s8 + q) * 64] : make_uint2(0xFF80FF80u, 0xFF80FF80u);      // -inf
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float f[4];
-        s2_unpack(v[q], f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (f[c] >= L && f[c] > -INFINITY) { atomicAdd(hist + (s8 + q) * 8 + half * 4 + c, 1); ++n; }
-        }
-      }
-    }
-  }
-  const int n_other = __shfl_xor(n, 32, 64);
-  const int n_user = n + n_other;
-  const bool is_hard = uvalid && n_user > S2_JMAX;
-  if (__ballot(is_hard)) {                                   // cold: a hard user's pairs are not emitted
-    if (is_hard) {
-      for (int st = 0; st < n_st; ++st) {
-        float f[4];
-        s2_unpack(mrow[(long)st * 64], f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (f[c] >= L && f[c] > -INFINITY) atomicSub(hist + st * 8 + half * 4 + c, 1);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- exclusive scan of the group counts -> offsets of the block's sorted pair list
-  {
-    const int per = (G + 1023) / 1024;
-    const int i0 = t * per, i1 = i0 + per < G ? i0 + per : G;
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += hist[i];
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const int v = t >= d ? part[t - d] : 0;
-      __syncthreads();
-      part[t] += v;
-      __syncthreads();
-    }
-    int run = part[t] - sum;
-    int* o = offs + (long)blockIdx.x * (G + 1);
-    for (int i = i0; i < i1; ++i) { const int c = hist[i]; hist[i] = run; o[i] = run; run += c; }
-    if (t == 1023) { hist[G] = part[1023]; o[G] = part[1023]; }
-  }
-  __syncthreads();
-  // ---- sweep B: scatter (hist[g] is now the running cursor of group g)
-  if (valid && !is_hard) {
-    int j = half ? n_other : 0;                              // the half-0 lane's pairs come first in the user's list
-    const long pbase = (long)blockIdx.x * S2_PAIRCAP;
-    for (int s8 = 0; s8 < n_st; s8 += 8) {
-      uint2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = s8 + q < n_st ? mrow[(long)(s8 + q) * 64] : make_uint2(0xFF80FF80u, 0xFF80FF80u);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float f[4];
-        s2_unpack(v[q], f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (f[c] >= L && f[c] > -INFINITY) {
-            const int pos = atomicAdd(hist + (s8 + q) * 8 + half * 4 + c, 1);
-            pairs[pbase + pos] = (int)user;
-            pair_of[user * S2_JMAX + j] = (int)(pbase + pos);
-            ++j;
-          }
-        }
-      }
-    }
-  }
   if (uvalid && half == 0) {
-    nsel[user] = is_hard ? 0 : n_user;
-    hard[user] = is_hard ? 1 : 0;
-    ovf_cnt[user] = 0;
-    Lout[user] = L;
+    Lout[user] = L; cnt[user] = 0; hard[user] = 0;
+    // the user's exclusion row for the final kernel (one dependent load chain less there)
+    long eb = 0, ee = 0;
+    if (indptr != nullptr) {
+      const long row = u_idx ? u_idx[user] : user;
+      eb = indptr[row];
+      ee = indptr[row + 1];
+    }
+    row_lo[user] = eb;
+    row_len[user] = (int)(ee - eb);
+  }
+  // one sweep: eight 16-byte rows (sixteen supertiles) in flight per lane; a ballot per class is the pair word of two groups
+  for (int s8 = 0; s8 < n_st2; s8 += 8) {
+    uint4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = s8 + q < n_st2 ? mrow[(long)(s8 + q) * 64] : make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float f[8];
+      s2_unpack8(v[q], f);
+      unsigned int my = 0u;                                  // lane e < 16 of the wave keeps the word of group slot e of this row
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned long long m = __ballot(f[e] >= L && f[e] > -INFINITY);
+        // supertile 2 (s8 + q) + (e >> 2), class e & 3: half 0 = lanes 0 .. 31, half 1 = lanes 32 .. 63
+        my = lane == e * 2 ? (unsigned int)m : my;
+        my = lane == e * 2 + 1 ? (unsigned int)(m >> 32) : my;
+      }
+      const int st = 2 * (s8 + q) + (lane >> 3);             // lane = (st & 1) * 8 + c * 2 + h
+      if (lane < 16 && s8 + q < n_st2 && st < n_st) {
+        const int g = st * 8 + (lane & 1) * 4 + ((lane >> 1) & 3);      // the sixteen lanes cover sixteen consecutive g: one 64-byte store
+        bitmap[unit * G + g] = my;
+      }
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // pass 2: re-score the selected (user, group) pairs, group by group
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Branch-free append of one accumulator value: lanes with a >= L store the raw entry (~item = il - OFF, score bits) at slot min(n, 3) of
-// their half region and count it. Slot 3 is the header slot: the 4th and later candidates of a lane land there and are overwritten by
-// the count afterwards (stores of one lane to one address complete in order); a count above 3 sends the lane through the overflow path.
+// Branch-free append of one accumulator value to the lane's PRIVATE slots in LDS (four entries of (~item, score bits) per lane and
+// MFMA block): lanes with a >= L write slot min(n, 3) and count. A fifth candidate of a 32-item half group overwrites the fourth — the
+// lane then reports its user as hard (massive ties only).
+#define S2_WCAP 256                      // candidate entries a wave collects (in LDS) before it flushes them to the users' lists
 template <int OFF>
-__device__ __forceinline__ void s2_try_append(float a, float L, int& n, int pos, unsigned int il, i32x4 rs) {
+__device__ __forceinline__ void s2_try_append(float a, float L, int& n, unsigned int priv, unsigned int il) {
   unsigned int tmp, t2;
   asm volatile(
       "v_cmpx_le_f32_e32 %[L], %[a]\n\t"
       "v_subrev_u32_e32 %[tmp], %[off], %[il]\n\t"
       "v_min_u32_e32 %[t2], 3, %[n]\n\t"
-      "v_lshl_add_u32 %[t2], %[t2], 3, %[pos]\n\t"
-      "buffer_store_dword %[tmp], %[t2], %[rs], 0 offen\n\t"
-      "buffer_store_dword %[a], %[t2], %[rs], 0 offen offset:4\n\t"
+      "v_lshl_add_u32 %[t2], %[t2], 3, %[priv]\n\t"
+      "ds_write2_b32 %[t2], %[tmp], %[a] offset1:1\n\t"
       "v_add_u32_e32 %[n], 1, %[n]\n\t"
       "s_mov_b64 exec, -1"
       : [n] "+v"(n), [tmp] "=&v"(tmp), [t2] "=&v"(t2)
-      : [a] "v"(a), [L] "v"(L), [il] "v"(il), [pos] "v"(pos), [rs] "s"(rs), [off] "n"(OFF)
+      : [a] "v"(a), [L] "v"(L), [il] "v"(il), [priv] "v"(priv), [off] "n"(OFF)
       : "vcc", "memory");
 }
 
-#define S2_CHUNK 1024                    // pairs of a work item staged in LDS at a time
-
 template <int KS>
-__global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __restrict__ U, const _Float16* __restrict__ It, int I, int item_offset,
-                                                            const float* __restrict__ Lbuf, const int* __restrict__ offs, const int* __restrict__ pairs,
-                                                            int n_blocks, int bps, int G, unsigned long long* __restrict__ cand,
-                                                            int* __restrict__ ovf_cnt, unsigned long long* __restrict__ ovf, int* __restrict__ hard) {
+__global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, int item_offset,
+                                                            const float* __restrict__ Lbuf, const unsigned int* __restrict__ bitmap, long n_units,
+                                                            int ups, int G, int* __restrict__ cnt, unsigned long long* __restrict__ cand,
+                                                            int* __restrict__ hard) {
   constexpr int D = KS * 16;
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
   constexpr int SWZ = (CPR >= 16) ? 15 : (CPR - 1);
   constexpr int PER_W = CPR / 4;                             // LDS-DMA instructions per wave for the 64-row item tile
   static_assert(PER_W >= 1, "D >= 32");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [64 rows][ROWB], segment tables, the staged pair chunk
-  int* segstart = (int*)(smem + 64 * ROWB);                  // [17]
-  int* segsrc = segstart + 32;                               // [16] first pair slot of the segment, relative to the superblock's first slot
-  int* ch_user = segsrc + 32;                                // [S2_CHUNK]
-  float* ch_L = (float*)(ch_user + S2_CHUNK);                // [S2_CHUNK]
-  int* ch_p = (int*)(ch_L + S2_CHUNK);                       // [S2_CHUNK] pair slot relative to the superblock's first slot
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [64 rows][ROWB] item tile | wave sums | staged users | private slots [4 waves][64 lanes][4] | the waves' collected lists
+  int* wsum = (int*)(smem + 64 * ROWB);                      // [8]
+  int* ch_user = wsum + 8;                                   // [S2_CHUNK]
+  unsigned long long* priv_all = (unsigned long long*)(ch_user + S2_CHUNK);      // [4][64][4]
+  unsigned long long* l_raw_all = priv_all + 4 * 64 * 4;     // [4][S2_WCAP]
+  int* l_user_all = (int*)(l_raw_all + 4 * S2_WCAP);         // [4][S2_WCAP]
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int sb = (int)(blockIdx.x / (unsigned int)G), g = (int)(blockIdx.x % (unsigned int)G);
   const int st = g >> 3, gh = (g >> 2) & 1, gc = g & 3;
-  const int b0 = sb * bps;
-  const int nb = n_blocks - b0 < bps ? n_blocks - b0 : bps;
-  if (t < 64) {
-    // segment lengths of the superblock's blocks for this group, prefix sum over the first 16 lanes
-    int s0 = 0, len = 0;
-    if (t < nb) {
-      const int* o = offs + (long)(b0 + t) * (G + 1) + g;
-      s0 = o[0];
-      len = o[1] - s0;
-    }
-    int incl = len;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(incl, d, 64); if ((t & 63) >= d) incl += v; }
-    if (t < 16) { segstart[t] = incl - len; segsrc[t] = t * S2_PAIRCAP + s0; }
-    if (t == 15) segstart[16] = incl;
-  }
-  __syncthreads();
-  const int total = segstart[16];
-  if (total == 0) return;                                    // workgroup-uniform
-  // the group's 64 item rows -> LDS (rows of the one-pass tile layout: 16-byte chunk cp of row i at chunk cp ^ (i & SWZ))
+  // the group's 64 item rows -> LDS first (rows of the one-pass tile layout: 16-byte chunk cp of row i at chunk cp ^ (i & SWZ)): the
+  // transfer runs under the set-up below
   const int item_base = st * S2_SUPER + 8 * gc + 4 * gh;     // item of element e: item_base + 32 (e >> 2) + (e & 3)
 #pragma unroll
   for (int q = 0; q < PER_W; ++q) {
@@ -524,59 +464,92 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(smem + (wave * PER_W + q) * 1024), 16, 0, 0);
   }
-  // candidate regions of this superblock through one buffer descriptor (offsets stay far below 4 GB)
-  const long cand_lo = (long)b0 * S2_PAIRCAP;                // first pair slot of the superblock
-  i32x4 rs;
-  {
-    const unsigned long long cb = (unsigned long long)(cand + cand_lo * 8);
-    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)cb);
-    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)(cb >> 32) & 0xFFFF);
-    rs[2] = (int)((long)nb * S2_PAIRCAP * 64);
-    rs[3] = 0x00020000;
-  }
-  const int* pairs_sb = pairs + cand_lo;
+  // the superblock's column of the bitmap: thread t holds the word of unit u0 + t (bit = user of the unit)
+  const long u0 = (long)sb * ups;
+  const unsigned int word = (t < ups && u0 + t < n_units) ? bitmap[(u0 + t) * G + g] : 0u;
+  const int nw = __popc(word);
+  int incl = nw;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  st_wait_vmcnt<0>();                                        // the item tile has landed (and the word)
+  __syncthreads();
+  const int w0s = wsum[0], w1s = wsum[1], w2s = wsum[2], w3s = wsum[3];
+  const int total = w0s + w1s + w2s + w3s;
+  if (total == 0) return;                                    // workgroup-uniform
+  const int first = incl - nw + (wave > 0 ? w0s : 0) + (wave > 1 ? w1s : 0) + (wave > 2 ? w2s : 0);      // position of this thread's first pair
   const unsigned char* rowp = smem + l31 * ROWB;
   const unsigned int lxh = (unsigned int)(((l31 & SWZ) << 4) ^ (half << 4));
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool tail_st = (st + 1) * S2_SUPER > I;              // the catalogue ends inside this supertile
   const int lane_item = item_base + 32 * half;               // element e = rb * 32 + (r & 3) + 8 (r >> 2) + 4 half: item lane_item + rb * 256 + (r >> 2) * 64 + (r & 3)
   const unsigned int il = 0xFFFFFFFFu - (unsigned int)(item_offset + lane_item);
+  unsigned long long* priv = priv_all + (wave * 64 + lane) * 4;
+  const unsigned int priv_addr = (unsigned int)(size_t)priv;
+  unsigned long long* l_raw = l_raw_all + wave * S2_WCAP;
+  int* l_user = l_user_all + wave * S2_WCAP;
+  int wn = 0;                                                // entries in this wave's list (wave-uniform)
+  // every collected candidate takes a slot of its user's list: one returning atomic each, the wave's in flight together
+  auto flush = [&]() {
+    st_wave_fence();
+    for (int e = lane; e < wn; e += 64) {
+      if (S2_ABL == 2) break;
+      const int user = l_user[e];
+      const int at = S2_ABL == 1 ? (e & 63) : atomicAdd(cnt + user, 1);
+      if (at < S2_CAND_CAP) cand[(long)user * S2_CAND_CAP + at] = l_raw[e];
+    }
+    st_wave_fence();
+    wn = 0;
+  };
   for (int c0 = 0; c0 < total; c0 += S2_CHUNK) {
     const int cn = total - c0 < S2_CHUNK ? total - c0 : S2_CHUNK;
-    // stage the chunk's pairs: slot, user, bound (two dependent loads per pair, all of the chunk's in flight together)
-    for (int q = t; q < cn; q += 256) {
-      const int qq = c0 + q;
-      int b = 0;
-#pragma unroll
-      for (int s_ = 1; s_ < 16; ++s_) b += qq >= segstart[s_] ? 1 : 0;
-      const int p = segsrc[b] + (qq - segstart[b]);
-      const int user = pairs_sb[p];
-      ch_p[q] = p;
-      ch_user[q] = user;
-      ch_L[q] = Lbuf[user];
-    }
-    st_wait_vmcnt<0>();                                      // (also the item tile's LDS-DMA of the first chunk)
-    __syncthreads();
-    for (int mb = wave; mb * 32 < cn; mb += 4) {
-      const int q = mb * 32 + l31;
-      const bool active = q < cn;
-      const int user = active ? ch_user[q] : 0;
-      const float L = active ? ch_L[q] : INFINITY;
-      const int p = active ? ch_p[q] : 0;
-      f16x8 ufrag[KS];
-      {
-        const f16x8* src = reinterpret_cast<const f16x8*>(U + (long)user * D);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
+    if (c0 > 0) __syncthreads();                             // the previous chunk's users have been consumed
+    // stage the chunk's users (expanding this thread's word)
+    {
+      unsigned int wbits = word;
+      int q = first;
+      while (wbits) {
+        const int b = __ffs((int)wbits) - 1;
+        wbits &= wbits - 1u;
+        if (q >= c0 && q < c0 + S2_CHUNK) ch_user[q - c0] = (int)((u0 + t) * 32 + b);
+        ++q;
       }
+    }
+    __syncthreads();
+    if (S2_ABL == 6) continue;
+    // the wave's MFMA blocks: 32 pairs each; the rows and the bound of the NEXT block are requested before the epilogue of the current one
+    f16x8 ufrag[KS];
+    int mb = wave;
+    int user = 0;
+    float L = INFINITY;
+    if (mb * 32 < cn) {
+      const int q = mb * 32 + l31;
+      user = S2_ABL == 3 ? l31 : ch_user[q < cn ? q : 0];
+      L = q < cn ? Lbuf[user] : INFINITY;
+      const f16x8* src = reinterpret_cast<const f16x8*>(U + (long)user * D);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
+    }
+    for (; mb * 32 < cn; mb += 4) {
+      const int cur_user = user;
+      const float cur_L = L;
       f32x16 acc[2];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const f16x8 af = *reinterpret_cast<const f16x8*>(rowp + rb * 32 * ROWB + (((unsigned int)s << 5) ^ lxh));
-          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, ufrag[s], s == 0 ? zero16 : acc[rb], 0, 0, 0);
+          if (S2_ABL == 5) { asm volatile("" ::"v"(af), "v"(ufrag[s])); acc[rb] = zero16; }      // lab: no MFMA
+          else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, ufrag[s], s == 0 ? zero16 : acc[rb], 0, 0, 0);
         }
+      }
+      if ((mb + 4) * 32 < cn) {
+        const int qn = (mb + 4) * 32 + l31;
+        user = S2_ABL == 3 ? l31 : ch_user[qn < cn ? qn : 0];
+        L = qn < cn ? Lbuf[user] : INFINITY;
+        const f16x8* src = reinterpret_cast<const f16x8*>(U + (long)user * D);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
       }
       if (tail_st) {
 #pragma unroll
@@ -585,40 +558,34 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
           for (int r = 0; r < 16; ++r) acc[rb][r] = lane_item + rb * 256 + (r >> 2) * 64 + (r & 3) < I ? acc[rb][r] : -INFINITY;
         }
       }
-      const int pos = p * 64 + half * 32;
       int n = 0;
-#define S2_AP(RB, R) s2_try_append<(RB) * 256 + ((R) >> 2) * 64 + ((R) & 3)>(acc[RB][R], L, n, pos, il, rs);
+      if (S2_ABL == 4 || S2_ABL == 5) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }      // lab: no epilogue
+#define S2_AP(RB, R) s2_try_append<(RB) * 256 + ((R) >> 2) * 64 + ((R) & 3)>(acc[RB][R], cur_L, n, priv_addr, il);
 #define S2_AP16(RB) S2_AP(RB, 0) S2_AP(RB, 1) S2_AP(RB, 2) S2_AP(RB, 3) S2_AP(RB, 4) S2_AP(RB, 5) S2_AP(RB, 6) S2_AP(RB, 7) \
                     S2_AP(RB, 8) S2_AP(RB, 9) S2_AP(RB, 10) S2_AP(RB, 11) S2_AP(RB, 12) S2_AP(RB, 13) S2_AP(RB, 14) S2_AP(RB, 15)
       S2_AP16(0)
       S2_AP16(1)
 #undef S2_AP16
 #undef S2_AP
-      if (active) cand[(cand_lo + p) * 8 + half * 4 + 3] = (unsigned long long)(unsigned int)n;      // header: the count
-      if (__ballot(n > 3)) {
-        // cold: a lane half with more than three candidates writes ALL of them to the user's overflow list (the final kernel ignores the
-        // region of a half whose count is above 3)
-        if (n > 3) {
+      // the block's candidates move from the private slots to the wave's list
+      if (n > 4) { hard[cur_user] = 1; n = 4; }              // a fifth candidate in one half group: the exact path takes the user
+      int incl_n = n;
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
+      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl_n, d, 64); if (lane >= d) incl_n += v; }
+      const int wave_n = __builtin_amdgcn_readlane(incl_n, 63);
+      if (wave_n > 0) {
+        if (wn + wave_n > S2_WCAP) flush();
+        int o = wn + incl_n - n;
+        st_wave_fence();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (acc[rb][r] >= L) {
-                const int o = atomicAdd(ovf_cnt + user, 1);
-                if (o < S2_OVF_CAP) {
-                  ovf[(long)user * S2_OVF_CAP + o] = ((unsigned long long)__float_as_uint(acc[rb][r]) << 32) |
-                                                     (unsigned long long)(il - (unsigned int)(rb * 256 + (r >> 2) * 64 + (r & 3)));
-                } else {
-                  hard[user] = 1;
-                }
-              }
-            }
-          }
+        for (int e = 0; e < 4; ++e) {
+          if (e < n) { l_raw[o] = priv[e]; l_user[o] = cur_user; ++o; }
         }
+        wn += wave_n;
       }
     }
-    __syncthreads();                                         // the chunk's staging arrays are free again
   }
+  flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -781,15 +748,12 @@ __device__ void s2_hard_user(const _Float16* __restrict__ U, const _Float16* __r
   s2_rank_write(stage, n, k, lane, out_val, out_idx);
 }
 
-#define S2_ROWCAP 256                     // exclusion-row entries a wave keeps in LDS (longer rows: binary search in memory)
-
 template <int KS>
 __global__ __launch_bounds__(256) void score_finalize2_kernel(const _Float16* __restrict__ U, const _Float16* __restrict__ It, long Bu, int I, int item_offset,
-                                                              int k, const long* __restrict__ u_idx, const long* __restrict__ indptr,
-                                                              const int* __restrict__ indices, const int* __restrict__ nsel, const int* __restrict__ hard,
-                                                              const int* __restrict__ ovf_cnt, const int* __restrict__ pair_of,
-                                                              const unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ ovf,
-                                                              float* __restrict__ out_val, int* __restrict__ out_idx) {
+                                                              int k, const long* __restrict__ row_lo, const int* __restrict__ row_len,
+                                                              const int* __restrict__ indices, const int* __restrict__ cnt, const int* __restrict__ hard,
+                                                              const unsigned long long* __restrict__ cand, float* __restrict__ out_val,
+                                                              int* __restrict__ out_idx) {
   __shared__ unsigned long long stage_all[4][S2_STAGE];
   __shared__ int row_all[4][S2_ROWCAP];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -797,82 +761,45 @@ __global__ __launch_bounds__(256) void score_finalize2_kernel(const _Float16* __
   if (user >= Bu) return;                                    // wave-uniform
   unsigned long long* stage = stage_all[w];
   int* rowbuf = row_all[w];
-  // everything the wave needs is requested up front; the only dependent chain is pair_of -> candidate regions
-  const int np = __builtin_amdgcn_readfirstlane(nsel[user]);
-  const int no = __builtin_amdgcn_readfirstlane(ovf_cnt[user]);
-  bool is_hard = __builtin_amdgcn_readfirstlane(hard[user]) != 0;
-  long eb = 0, ee = 0;
-  if (indptr != nullptr) {
-    const long row = u_idx ? u_idx[user] : user;
-    eb = indptr[row];
-    ee = indptr[row + 1];
-  }
-  const int rowlen = (int)(ee - eb);
+  const int nc = __builtin_amdgcn_readfirstlane(cnt[user]);
+  bool is_hard = __builtin_amdgcn_readfirstlane(hard[user]) != 0 || nc > S2_CAND_CAP;
+  const long eb = row_lo[user];                              // the user's exclusion row (bounds looked up by the selection kernel)
+  const int rowlen = __builtin_amdgcn_readfirstlane(row_len[user]);
+  const long ee = eb + rowlen;
   const bool row_lds = rowlen <= S2_ROWCAP;
   float* ov = out_val + user * k;
   int* oi = out_idx + user * k;
   int n = 0;
   if (!is_hard) {
-    const int p0 = lane < np ? pair_of[user * S2_JMAX + lane] : 0;
-    const int p1 = lane + 64 < np ? pair_of[user * S2_JMAX + 64 + lane] : 0;
+    // the candidate list (at most two entries per lane) and the exclusion row are requested together
+    const unsigned long long* list = cand + user * S2_CAND_CAP;
+    unsigned long long raw[S2_CAND_CAP / 64];
+#pragma unroll
+    for (int i = 0; i < S2_CAND_CAP / 64; ++i) raw[i] = i * 64 + lane < nc ? list[i * 64 + lane] : 0ull;
     if (row_lds) {
       for (int i = lane; i < rowlen; i += 64) rowbuf[i] = indices[eb + i];
     }
-    auto take = [&](unsigned long long raw, bool ok) {
-      const bool keep = ok && raw != 0ull;
+    st_wave_fence();
+#pragma unroll
+    for (int i = 0; i < S2_CAND_CAP / 64; ++i) {
+      bool keep = raw[i] != 0ull;
+      if (keep && rowlen > 0) {
+        // exclusion filter (pass 2 does not see exclusions): binary search in the user's sorted CSR row
+        const int item = (int)(0xFFFFFFFFu - (unsigned int)(raw[i] & 0xFFFFFFFFull));
+        if (row_lds) {
+          int lo = 0, hi = rowlen;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; const int v = rowbuf[mid]; if (v < item) lo = mid + 1; else hi = mid; }
+          keep = !(lo < rowlen && rowbuf[lo] == item);
+        } else {
+          keep = !s2_excluded(indices, eb, ee, item);
+        }
+      }
       const unsigned long long m = __ballot(keep);
       const int p = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-      if (keep && p < S2_STAGE) stage[p] = raw;
+      if (keep) stage[p] = raw[i];
       n += __popcll(m);
-    };
-    const int nslots = np * 8;                               // 64-byte region per pair: slots 0-2 / 4-6 entries, 3 / 7 the two halves' counts
-    for (int base = 0; base < nslots; base += 256) {
-      unsigned long long raw[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int sl = base + i * 64 + lane;
-        const int pair = sl >> 3;
-        const int pa = __shfl(p0, pair & 63, 64), pb = __shfl(p1, pair & 63, 64);
-        raw[i] = sl < nslots ? cand[(long)(pair < 64 ? pa : pb) * 8 + (sl & 7)] : 0ull;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int sl = base + i * 64 + lane;
-        const int hdr = __shfl((int)(unsigned int)raw[i], (lane & ~3) | 3, 64);        // the count of this slot's half: slot 3 / 7 of the pair
-        take(raw[i], sl < nslots && (lane & 3) < 3 && (lane & 3) < hdr && hdr <= 3);
-      }
     }
-    if (no > 0) {
-      const int m = no < S2_OVF_CAP ? no : S2_OVF_CAP;
-      for (int i0 = 0; i0 < m; i0 += 64) take(i0 + lane < m ? ovf[user * S2_OVF_CAP + i0 + lane] : 0ull, i0 + lane < m);
-    }
-    if (n > S2_STAGE) is_hard = true;
     st_wave_fence();
-    if (!is_hard && rowlen > 0) {
-      // exclusion filter (pass 2 does not see exclusions): every staged candidate against the user's sorted CSR row, in place
-      int n2 = 0;
-      for (int c0 = 0; c0 < n; c0 += 64) {
-        const unsigned long long raw = c0 + lane < n ? stage[c0 + lane] : 0ull;
-        const int item = (int)(0xFFFFFFFFu - (unsigned int)(raw & 0xFFFFFFFFull));
-        bool keep = raw != 0ull;
-        if (keep) {
-          if (row_lds) {
-            int lo = 0, hi = rowlen;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; const int v = rowbuf[mid]; if (v < item) lo = mid + 1; else hi = mid; }
-            keep = !(lo < rowlen && rowbuf[lo] == item);
-          } else {
-            keep = !s2_excluded(indices, eb, ee, item);
-          }
-        }
-        const unsigned long long m = __ballot(keep);
-        const int p = n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-        st_wave_fence();
-        if (keep) stage[p] = raw;                            // p <= c0 + lane: nothing unread is overwritten
-        n2 += __popcll(m);
-      }
-      n = n2;
-      st_wave_fence();
-    }
     if (n < k) is_hard = true;                               // fewer than k: the catalogue holds fewer than k scoreable items (or a bug) — the exact path decides
   }
   if (is_hard) {
@@ -888,8 +815,8 @@ __global__ __launch_bounds__(256) void score_finalize2_kernel(const _Float16* __
 static long s2_al(long b) { return (b + 255) & ~255L; }
 
 struct S2Layout {
-  long n_units, m_units, n_blocks, n_st, G;
-  long off_M, off_L, off_L2, off_nsel, off_hard, off_ovfc, off_pairof, off_offs, off_pairs, off_cand, off_ovf, total;
+  long n_units, m_units, nu_pad, n_st, n_st2, G;
+  long off_M, off_L, off_L2, off_cnt, off_hard, off_rowlo, off_rowlen, off_bitmap, off_cand, total;
 };
 
 static S2Layout s2_layout(long Bu, int I, const S5Plan& plan) {
@@ -898,30 +825,29 @@ static S2Layout s2_layout(long Bu, int I, const S5Plan& plan) {
   const long rem_units = plan.n_part > 0 ? plan.n_part / plan.P : 0;
   l.m_units = (long)plan.n_wg * plan.W + rem_units;          // rows of M the pass-1 grid can write (>= n_units)
   if (l.m_units < l.n_units) l.m_units = l.n_units;
-  l.n_blocks = sbr_cdiv(l.n_units, S2_BU);
+  l.nu_pad = (l.n_units + 63) & ~63L;                        // row length of the bitmap in words
   l.n_st = sbr_cdiv(I, S2_SUPER);
+  l.n_st2 = (l.n_st + 1) / 2;
   l.G = l.n_st * 8;
-  const long users = l.n_blocks * S2_BLOCK_USERS;
+  const long users = l.n_units * 32;
   long o = 0;
-  l.off_M = o; o += s2_al(l.m_units * l.n_st * 64 * 8);
+  l.off_M = o; o += s2_al(l.m_units * l.n_st2 * 64 * 16);
   l.off_L = o; o += s2_al(users * 4);
   l.off_L2 = o; o += s2_al(users * 4);
-  l.off_nsel = o; o += s2_al(users * 4);
+  l.off_cnt = o; o += s2_al(users * 4);
   l.off_hard = o; o += s2_al(users * 4);
-  l.off_ovfc = o; o += s2_al(users * 4);
-  l.off_pairof = o; o += s2_al(users * S2_JMAX * 4);
-  l.off_offs = o; o += s2_al(l.n_blocks * (l.G + 1) * 4);
-  l.off_pairs = o; o += s2_al(l.n_blocks * S2_PAIRCAP * 4);
-  l.off_cand = o; o += s2_al(l.n_blocks * S2_PAIRCAP * 64);
-  l.off_ovf = o; o += s2_al(users * S2_OVF_CAP * 8);
+  l.off_rowlo = o; o += s2_al(users * 8);
+  l.off_rowlen = o; o += s2_al(users * 4);
+  l.off_bitmap = o; o += s2_al(l.G * l.n_units * 4);
+  l.off_cand = o; o += s2_al(users * S2_CAND_CAP * 8);
   l.total = o + 256;
   return l;
 }
 
 bool s2_supported(int D, long Bu, int I, int k) {
   if (!(D == 64 || D == 128 || D == 256) || k < 1 || k > 32 || Bu < 1) return false;
-  if (I < S2_MIN_ITEMS || sbr_cdiv(I, S2_SUPER) * 8 > S2_MAX_GROUPS) return false;
-  return true;
+  if (I < S2_MIN_ITEMS || Bu > 4000000L) return false;       // (candidate lists behind one buffer descriptor: < 4 GB)
+  return sbr_cdiv(Bu, D >= 256 ? 4096 : 8192) * (long)sbr_cdiv(I, S2_SUPER) * 8 < (1L << 31);
 }
 
 long s2_workspace_bytes(long Bu, int I) { return s2_layout(Bu, I, s5_plan(Bu)).total; }
@@ -936,17 +862,15 @@ static int s2_launch(const void* U, const void* It, long Bu, int I, const long* 
   SBR_REQUIRE(workspace && workspace_bytes >= l.total, "sbr_score_topk_f16: workspace of %ld bytes needed (sbr_score_topk_f16_workspace), %ld given",
               l.total, workspace_bytes);
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  uint2* M = (uint2*)(ws + l.off_M);
+  uint4* M = (uint4*)(ws + l.off_M);
   float* Lb = (float*)(ws + l.off_L);
   float* Lb2 = (float*)(ws + l.off_L2);
-  int* nsel = (int*)(ws + l.off_nsel);
+  int* cnt = (int*)(ws + l.off_cnt);
   int* hard = (int*)(ws + l.off_hard);
-  int* ovfc = (int*)(ws + l.off_ovfc);
-  int* pair_of = (int*)(ws + l.off_pairof);
-  int* offs = (int*)(ws + l.off_offs);
-  int* pairs = (int*)(ws + l.off_pairs);
+  long* row_lo = (long*)(ws + l.off_rowlo);
+  int* row_len = (int*)(ws + l.off_rowlen);
+  unsigned int* bitmap = (unsigned int*)(ws + l.off_bitmap);
   unsigned long long* cand = (unsigned long long*)(ws + l.off_cand);
-  unsigned long long* ovf = (unsigned long long*)(ws + l.off_ovf);
   const bool with_excl = eptr != nullptr && excl_nnz > 0;
   S5Events evs = {nullptr, nullptr};
   if (with_excl) {
@@ -968,30 +892,27 @@ static int s2_launch(const void* U, const void* It, long Bu, int I, const long* 
   }
   // ---- selection
   {
-    const size_t lds = (size_t)(l.G + 1) * 4;
-    if (hipFuncSetAttribute((const void*)score_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      sbr_set_error("sbr_score_topk_f16 (two-pass): cannot raise the dynamic LDS limit of the selection kernel");
-      return SBR_ERR_HIP;
-    }
     const long n_full_units = plan.n_part > 0 ? (long)plan.n_wg * plan.W : (1L << 40);
-    score_select_kernel<<<(unsigned int)l.n_blocks, 1024, lds, s>>>(M, Lb, l.n_units, n_full_units, (int)l.n_st, Bu, k, nsel, hard, ovfc, pair_of, offs,
-                                                                      pairs, Lb2);
+    score_select_kernel<<<(unsigned int)sbr_cdiv(l.n_units, 4), 256, 0, s>>>(M, Lb, l.n_units, (int)l.G, n_full_units, (int)l.n_st, Bu, k, u_idx,
+                                                                               with_excl ? eptr : nullptr, bitmap, Lb2, cnt, hard, row_lo, row_len);
     SBR_CHECK_LAUNCH("sbr_score_topk_f16 (two-pass, selection)");
   }
   // ---- pass 2
   {
-    const int bps = D >= 256 ? 8 : 16;                       // selection blocks per superblock: 4,096 / 8,192 users = 2 MB of rows
-    const long n_sb = sbr_cdiv(l.n_blocks, bps);
-    const size_t lds = (size_t)64 * D * 2 + 64 * 4 + (size_t)S2_CHUNK * 12;
-    SBR_REQUIRE(n_sb * l.G < (1L << 31), "sbr_score_topk_f16 (two-pass): grid too large");
-    score_rescore_kernel<KS><<<(unsigned int)(n_sb * l.G), 256, lds, s>>>((const _Float16*)U, (const _Float16*)It, I, item_offset, Lb2, offs, pairs,
-                                                                            (int)l.n_blocks, bps, (int)l.G, cand, ovfc, ovf, hard);
+#ifdef S2_UPS
+    const int ups = S2_UPS;                                  // lab
+#else
+    const int ups = D >= 256 ? 128 : 256;                    // units per superblock: 4,096 / 8,192 users = 2 MB of rows
+#endif
+    const long n_sb = sbr_cdiv(l.n_units, ups);
+    const size_t lds = (size_t)64 * D * 2 + 32 + (size_t)S2_CHUNK * 4 + 4 * 64 * 4 * 8 + (size_t)4 * S2_WCAP * 12;
+    score_rescore_kernel<KS><<<(unsigned int)(n_sb * l.G), 256, lds, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, item_offset, Lb2, bitmap,
+                                                                            l.n_units, ups, (int)l.G, cnt, cand, hard);
     SBR_CHECK_LAUNCH("sbr_score_topk_f16 (two-pass, pass 2)");
   }
   // ---- final selection
-  score_finalize2_kernel<KS><<<(unsigned int)sbr_cdiv(Bu, 4), 256, 0, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, item_offset, k, u_idx,
-                                                                             with_excl ? eptr : nullptr, eidx, nsel, hard, ovfc, pair_of, cand, ovf,
-                                                                             out_val, out_idx);
+  score_finalize2_kernel<KS><<<(unsigned int)sbr_cdiv(Bu, 4), 256, 0, s>>>((const _Float16*)U, (const _Float16*)It, Bu, I, item_offset, k,
+                                                                             row_lo, row_len, eidx, cnt, hard, cand, out_val, out_idx);
   SBR_CHECK_LAUNCH("sbr_score_topk_f16 (two-pass, final selection)");
   return SBR_OK;
 }
