@@ -236,18 +236,18 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def _pmc_file():
-    """The newest committed PMC summary (profiles/rNN_bench_hbm_traffic.csv, written by tools/profile_round.sh + make_profiles.py)."""
+def _pmc_file(cfg=''):
+    """The newest committed PMC summary (profiles/rNN[_c5|_c3]_bench_hbm_traffic.csv, written by tools/profile_round.sh + make_profiles.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench_hbm_traffic.csv')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]{cfg}_bench_hbm_traffic.csv')))
     return files[-1] if files else None
 
 
-def _pmc_rows():
+def _pmc_rows(cfg=''):
     """-> (relative path, csrc hash the summary was collected with | None, rows)"""
     import csv
     import re
-    path = _pmc_file()
+    path = _pmc_file(cfg)
     if path is None:
         return None, None, []
     lines = open(path).read().splitlines()
@@ -276,9 +276,10 @@ def pmc_symbol_traffic(sym, batch, one_shape=True):
     return sum(h[0] * h[1] for h in hit) / n * 1e6, note
 
 
-def pmc_scorer_traffic(n_users):
-    """HBM bytes of one fused scoring launch over the c2 catalogue from the same PMC passes (None for another shape)."""
-    path, sha, rows = _pmc_rows()
+def pmc_scorer_traffic(n_users, cfg=''):
+    """HBM bytes of one fused scoring launch from the PMC passes of the same command: over the c2 catalogue (cfg '') or the c5 shard
+    shape ('_c5': bench.py --only c5); None for another shape."""
+    path, sha, rows = _pmc_rows(cfg)
     if path is None or n_users != C2['n_users']:
         return None, None
     for r in rows:
@@ -488,7 +489,7 @@ def bench_c5_shard(S, device, k=20, reps=12, warm=6):
     return {'workload': 'BASELINE configs[4], one of eight item shards: 100k users x 25k items x 256 fp16, 50 exclusions per user, top-20',
             'value': round(U * I / dt, 1), 'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3),
             'ms_per_call_with_mask_conversion': round(build_ms, 4),
-            'roofline': scoring_roofline(U, I, D, k, avg_ms)}
+            'roofline': scoring_roofline(U, I, D, k, avg_ms, *pmc_scorer_traffic(U, '_c5'))}
 
 
 def host_cores():
@@ -983,6 +984,8 @@ def main():
     ap.add_argument('--no-c1', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the c3 and c5-shard objects')
     ap.add_argument('--small', action='store_true', help='1/10-size workload (debug only; never a reportable number)')
+    ap.add_argument('--only', choices=['c3', 'c5'], default=None,
+                    help='profiling passes (tools/profile_round.sh): run ONLY the c3 step (B = 4096) or the c5 shard scoring and print its object')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -1034,6 +1037,14 @@ def main():
             raise SystemExit(f'bench.py: backend {backend_used!r} is not RCCL')
 
     import sibrar_amd as S
+    if args.only is not None:
+        if world != 1:
+            raise SystemExit('bench.py --only runs on one GPU')
+        obj = bench_c5_shard(S, device) if args.only == 'c5' else bench_c3(S, device, args.steps)
+        if 'roofline' in obj:
+            obj['roofline'] = compact_roofline(obj['roofline'])
+        print(json.dumps({'only': args.only, args.only: obj, 'tables': write_tables()}))
+        return
     cfg = dict(C2)
     if args.small:
         cfg.update(n_users=10_000, n_items=5_000, nnz=500_000)

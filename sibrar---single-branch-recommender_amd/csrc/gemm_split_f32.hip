@@ -68,6 +68,16 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
     long row = (long)blk * 32 + l31;
     if (row >= g.M) row = g.M - 1;                               // rows past the end are computed on a valid row and never stored
     const float* p = g.A + row * g.lda + h * 64 + half * 8;
+#ifdef SP_ABL_COALESCED       /* lab (timing only, wrong results): the same bytes of the block with whole-line wave instructions */
+    const float* pc = g.A + (long)blk * 32 * g.lda + h * 2048 + lane * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      raw[s][0] = *reinterpret_cast<const float4*>(pc + (2 * s) * 256);
+      raw[s][1] = *reinterpret_cast<const float4*>(pc + (2 * s + 1) * 256);
+    }
+    (void)p;
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       raw[s][0] = *reinterpret_cast<const float4*>(p + s * 16);

@@ -527,8 +527,17 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
       user = S2_ABL == 3 ? l31 : ch_user[q < cn ? q : 0];
       L = q < cn ? Lbuf[user] : INFINITY;
       const f16x8* src = reinterpret_cast<const f16x8*>(U + (long)user * D);
+      if (S2_ABL == 7) {
+        // lab (timing only): the same rows with whole-row wave instructions — instruction s reads rows 4 s .. 4 s + 3 of the block, 16 lanes per row
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int qq = mb * 32 + (4 * s + (lane >> 4)) % 32;
+          ufrag[s] = reinterpret_cast<const f16x8*>(U + (long)ch_user[qq < cn ? qq : 0] * D)[lane & 15];
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
+      }
     }
     for (; mb * 32 < cn; mb += 4) {
       const int cur_user = user;
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const f16x8 af = *reinterpret_cast<const f16x8*>(rowp + rb * 32 * ROWB + (((unsigned int)s << 5) ^ lxh));
-          if (S2_ABL == 5) { asm volatile("" ::"v"(af), "v"(ufrag[s])); acc[rb] = zero16; }      // lab: no MFMA
+          if (S2_ABL == 5 || S2_ABL == 7) { asm volatile("" ::"v"(af), "v"(ufrag[s])); acc[rb] = zero16; }      // lab: no MFMA
           else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, ufrag[s], s == 0 ? zero16 : acc[rb], 0, 0, 0);
         }
       }
@@ -548,8 +557,16 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
         user = S2_ABL == 3 ? l31 : ch_user[qn < cn ? qn : 0];
         L = qn < cn ? Lbuf[user] : INFINITY;
         const f16x8* src = reinterpret_cast<const f16x8*>(U + (long)user * D);
+        if (S2_ABL == 7) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const int qq = (mb + 4) * 32 + (4 * s + (lane >> 4)) % 32;
+            ufrag[s] = reinterpret_cast<const f16x8*>(U + (long)ch_user[qq < cn ? qq : 0] * D)[lane & 15];
+          }
+        } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) ufrag[s] = src[2 * s + half];
+        }
       }
       if (tail_st) {
 #pragma unroll
@@ -559,7 +576,7 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(const _Float16* __re
         }
       }
       int n = 0;
-      if (S2_ABL == 4 || S2_ABL == 5) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }      // lab: no epilogue
+      if (S2_ABL == 4 || S2_ABL == 5 || S2_ABL == 7) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }      // lab: no epilogue
 #define S2_AP(RB, R) s2_try_append<(RB) * 256 + ((R) >> 2) * 64 + ((R) & 3)>(acc[RB][R], cur_L, n, priv_addr, il);
 #define S2_AP16(RB) S2_AP(RB, 0) S2_AP(RB, 1) S2_AP(RB, 2) S2_AP(RB, 3) S2_AP(RB, 4) S2_AP(RB, 5) S2_AP(RB, 6) S2_AP(RB, 7) \
                     S2_AP(RB, 8) S2_AP(RB, 9) S2_AP(RB, 10) S2_AP(RB, 11) S2_AP(RB, 12) S2_AP(RB, 13) S2_AP(RB, 14) S2_AP(RB, 15)

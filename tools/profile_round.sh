@@ -19,3 +19,16 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_
 echo "mfma pass done"
 grep '^{' $O/stats.log | tail -1 > $O/bench_line.json || true
 python3 tools/make_profiles.py $O $TAG
+# ---- the other one-GPU configurations at their own shapes: the c5 shard (100k x 25k x 256 scoring) and the c3 step (B = 4096)
+for CFG in c5 c3; do
+  P=$O/$CFG
+  mkdir -p $P
+  CARGS="bench.py --only $CFG --steps 30 --warmup 5"
+  rocprofv3 --kernel-trace --stats -d $P/stats -o bench --output-format csv -- python3 $CARGS > $P/stats.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $P/fetch -o bench --output-format csv -- python3 $CARGS > $P/fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/write -o bench --output-format csv -- python3 $CARGS > $P/write.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/mfma -o bench --output-format csv -- python3 $CARGS > $P/mfma.log 2>&1
+  grep '^{' $P/stats.log | tail -1 > $P/bench_line.json || true
+  python3 tools/make_profiles.py $P ${TAG}_$CFG
+  echo "$CFG passes done"
+done
