@@ -30,6 +30,9 @@
 #define SP_N 128
 #define SP_K 128
 #define SP_WAVES 8
+#ifndef SPM_WAVES
+#define SPM_WAVES 8                         // waves per workgroup of the K = N = 128 kernel (the projector kernel keeps SP_WAVES)
+#endif
 #define SP_PLANE (4 * 8 * 64 * 16)           // bytes of one bf16 plane of W in fragment order: [4 column tiles][8 k steps][64 lanes][8 bf16]
 
 struct SplitArgs {
@@ -52,7 +55,7 @@ struct SplitArgs {
 // EPI 2 (MODE 0): EPI 0 + per-column sums and sums of squares of what is stored (the batch statistics of a BatchNorm that follows,
 // left pending in colsum_ws in the replica layout of sbr_col_reduce<2>: the separate statistics pass over the output is not needed).
 template <int MODE, int EPI>
-__global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs g, int n_blocks) {
+__global__ __launch_bounds__(64 * SPM_WAVES, 1) void gemm_split_kernel(SplitArgs g, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -61,7 +64,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
   // Block -> wave: SIMD sid = 4 blockIdx + (wave & 3) of the chip takes blocks sid, sid + S, sid + 2 S, ... (S = SIMDs in the grid),
   // alternating between its two waves, so that the matrix pipes - the shared resource of the two waves - get equal block counts
   // (2,816 blocks over 1,024 pipes: 3 or 2 each; numbering the waves 8 blockIdx + wave would give 4 or 2).
-  const int gw = (wave >> 2) * (gridDim.x * 4) + blockIdx.x * 4 + (wave & 3), nw = gridDim.x * SP_WAVES;
+#if SPM_WAVES == 8
+  const int gw = (wave >> 2) * (gridDim.x * 4) + blockIdx.x * 4 + (wave & 3), nw = gridDim.x * SPM_WAVES;
+#else
+  const int gw = wave * gridDim.x + blockIdx.x, nw = gridDim.x * SPM_WAVES;
+#endif
 
   // raw A of one half block: k steps 4 h .. 4 h + 3, per step the 8 floats k = 16 s + 8 half .. + 7 of row l31 of the block
   auto load_half = [&](int blk, int h, float4 (&raw)[4][2]) {
@@ -89,22 +96,24 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
 
   // ---- set-up: the weight as three bf16 planes in fragment order. Chunk (n, kc) = the 8 values W(n, 8 kc .. 8 kc + 7) is the operand
   // of lane (n & 31) + 32 (kc & 1) in fragment (column tile n >> 5, k step kc >> 1). 2048 chunks, 4 per thread.
+  constexpr int SETUP_IT = (2048 + 64 * SPM_WAVES - 1) / (64 * SPM_WAVES);
 #pragma unroll
-  for (int i = 0; i < 2048 / (64 * SP_WAVES); ++i) {
+  for (int i = 0; i < SETUP_IT; ++i) {
     int n, kc;
     float4 lo, hi;
+    if (SPM_WAVES != 8 && (MODE == 0 ? wave + i * SPM_WAVES >= 32 : t + i * 64 * SPM_WAVES >= 2048)) break;
     if constexpr (MODE == 0) {
       // rows of W are contiguous in k. A wave-instruction handles ONE operand fragment (column tile j, k step ks): lane L reads the
       // 8 values W(32 j + (L & 31), 16 ks + 8 (L >> 5) .. + 7) and writes its 16 bytes at lane position L of the fragment —
       // consecutive lanes, consecutive LDS addresses. (Thread order along k — 16 consecutive threads per row — makes 16 lanes write
       // 512 bytes apart: a 16-way bank conflict on every ds_write_b128 of the set-up.)
-      const int f = wave * 4 + i;                                // fragments 4 w .. 4 w + 3 of the 32
+      const int f = SPM_WAVES == 8 ? wave * 4 + i : wave + i * SPM_WAVES;      // fragments 4 w .. 4 w + 3 of the 32 (eight waves)
       n = (f >> 3) * 32 + l31; kc = (f & 7) * 2 + half;
       const float* p = g.W + (long)n * g.ldw + kc * 8;
       lo = *reinterpret_cast<const float4*>(p);
       hi = *reinterpret_cast<const float4*>(p + 4);
     } else {                                                     // rows of W are contiguous in n: consecutive threads read consecutive n
-      const int c = t + i * 64 * SP_WAVES;
+      const int c = t + i * 64 * SPM_WAVES;
       n = c & 127; kc = c >> 7;
       const float* p = g.W + (long)(kc * 8) * g.ldw + n;
       lo = make_float4(p[0], p[g.ldw], p[2 * g.ldw], p[3 * g.ldw]);
@@ -207,7 +216,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_kernel(SplitArgs 
           if constexpr (EPI == 2) {
             if (FULL || lr < rows_left) { ts += v; tq += v * v; }
           }
+#ifdef SP_ABL_NOSTORE       /* lab (timing only): the epilogue stores nothing */
+          asm volatile("" ::"v"(v));
+#else
           if (FULL || lr < rows_left) cp[(long)lr * g.ldc + j * 32] = v;
+#endif
         }
         if constexpr (KIND == 3 || EPI == 2) cs[j] += (double)ts;
         if constexpr (EPI == 2) cq[j] += (double)tq;
@@ -311,7 +324,7 @@ static int gemm_split_impl(int mode, const float* A, long lda, const float* W, l
   g.fin_running_mean = fin ? fin->running_mean : nullptr; g.fin_running_var = fin ? fin->running_var : nullptr;
   g.fin_nbt = fin ? fin->nbt : nullptr; g.fin_eps = fin ? fin->eps : 0.f; g.fin_momentum = fin ? fin->momentum : 0.f;
   const int n_blocks = sbr_cdiv(M, 32);
-  int grid = sbr_cdiv(n_blocks, SP_WAVES);
+  int grid = sbr_cdiv(n_blocks, SPM_WAVES);
   if (grid > 256) grid = 256;
   const size_t lds = 3 * SP_PLANE;
   hipStream_t s = (hipStream_t)stream;
@@ -324,7 +337,7 @@ static int gemm_split_impl(int mode, const float* A, long lda, const float* W, l
         return SBR_ERR_HIP;                                                                                                \
       }                                                                                                                    \
     }                                                                                                                      \
-    gemm_split_kernel<MODE, EPI><<<grid, 64 * SP_WAVES, lds, s>>>(g, n_blocks);                                            \
+    gemm_split_kernel<MODE, EPI><<<grid, 64 * SPM_WAVES, lds, s>>>(g, n_blocks);                                            \
   } while (0)
   if (mode == 0 && colsum_ws) SP_LAUNCH(0, 2);
   else if (mode == 0) SP_LAUNCH(0, 0);
