@@ -380,6 +380,9 @@ extern "C" int sbr_gemm_split_bnstats_f32(const float* A, long lda, const float*
 #ifndef PJ_ABL
 #define PJ_ABL 0                         // lab (timing only): 2 weight planes written once, 3 the first two A chunks only, 4 = 2 + 3, 5 no A split
 #endif
+#ifndef PJ_ALLHALF
+#define PJ_ALLHALF 0                     // 1: EVERY block is shared by the two waves of a SIMD (64 output columns each)
+#endif
 struct ProjArgs {
   const float* A; long lda; const int* a_idx;
   const float* W; long ldw;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int gw = (wave >> 2) * (gridDim.x * 4) + blockIdx.x * 4 + (wave & 3), nw = gridDim.x * SP_WAVES;
-  const int n_it = (n_blocks + nw - 1) / nw;
+  const int n_it = PJ_ALLHALF ? (n_blocks + gridDim.x * 4 - 1) / (gridDim.x * 4) : (n_blocks + nw - 1) / nw;
   const int KC = g.K / PJ_KC;
   constexpr int PL = 4 * 4 * 64 * 16;                            // bytes of one plane of a chunk
   // Work items. A round hands out nw blocks of 32 rows: the first S = nw / 2 to waves 0-3 (one per SIMD), the rest to waves 4-7
@@ -413,6 +416,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, 1) void gemm_split_proj_kernel(ProjA
   const bool half_mode = rem > S && 2 * rem <= 3 * S;
   const int hs = blockIdx.x * 4 + (wave & 3);                    // half item of this wave (waves 4-7, last round, half mode)
 #define PJ_ITEM(it_, blk_, jlo_, jhi_, valid_) do { \
+    if (PJ_ALLHALF) { \
+      blk_ = (it_) * S + blockIdx.x * 4 + (wave & 3); jlo_ = wave >> 2; jhi_ = (wave >> 2) + 1; valid_ = blk_ < n_blocks; \
+    } else \
     if ((it_) == last_it && half_mode && wave >= 4) { \
       blk_ = last_it * nw + S + (hs >> 1); jlo_ = hs & 1; jhi_ = (hs & 1) + 1; valid_ = S + (hs >> 1) < rem; \
     } else { \

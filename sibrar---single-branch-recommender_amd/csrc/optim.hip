@@ -40,6 +40,24 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
                              long n, AdamHyper h, float step_size, float bc2_sqrt, const double* __restrict__ cp_src = nullptr,
                              double* __restrict__ cp_dst = nullptr, int cp_n = 0) {
   if (blockIdx.x == 0 && (int)threadIdx.x < cp_n) cp_dst[threadIdx.x] = cp_src[threadIdx.x];
+  if ((n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
+    // 16 bytes per lane; the same per-element function, bit for bit
+    for (long e4 = blockIdx.x * (long)blockDim.x + threadIdx.x; e4 < (n >> 2); e4 += (long)gridDim.x * blockDim.x) {
+      const long e = e4 << 2;
+      float4 pe = *reinterpret_cast<const float4*>(p + e), me = *reinterpret_cast<const float4*>(m + e), ve = *reinterpret_cast<const float4*>(v + e);
+      const float4 ge = *reinterpret_cast<const float4*>(g + e);
+      adam_element(pe.x, ge.x, me.x, ve.x, h, step_size, bc2_sqrt);
+      adam_element(pe.y, ge.y, me.y, ve.y, h, step_size, bc2_sqrt);
+      adam_element(pe.z, ge.z, me.z, ve.z, h, step_size, bc2_sqrt);
+      adam_element(pe.w, ge.w, me.w, ve.w, h, step_size, bc2_sqrt);
+      *reinterpret_cast<float4*>(p + e) = pe;
+      *reinterpret_cast<float4*>(m + e) = me;
+      *reinterpret_cast<float4*>(v + e) = ve;
+      if (ZERO && (__float_as_uint(ge.x) | __float_as_uint(ge.y) | __float_as_uint(ge.z) | __float_as_uint(ge.w)) != 0u)
+        *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float pe = p[e], me = m[e], ve = v[e];
     const float ge = g[e];
@@ -240,6 +258,27 @@ __global__ __launch_bounds__(256) void adam_step_rows_kernel(float* __restrict__
     return;
   }
   const long span = hi - lo, n_rest = n - span;
+  if (((lo | hi | n) & 3) == 0) {
+    // 16 bytes per lane (the flat buffers' segments are 256-byte aligned: a quad never straddles the table): a quarter of the memory
+    // instructions of the element loop below for the same bytes; the arithmetic per element is the same function, bit for bit
+    const long n4 = n_rest >> 2;
+    for (long d4 = idx * (long)blockDim.x + threadIdx.x; d4 < n4; d4 += (long)n_dense * blockDim.x) {
+      const long d = d4 << 2;
+      const long e = d < lo ? d : d + span;
+      float4 pe = *reinterpret_cast<const float4*>(p + e), me = *reinterpret_cast<const float4*>(m + e), ve = *reinterpret_cast<const float4*>(v + e);
+      const float4 ge = *reinterpret_cast<const float4*>(g + e);
+      adam_element(pe.x, ge.x, me.x, ve.x, h, step_size, bc2_sqrt);
+      adam_element(pe.y, ge.y, me.y, ve.y, h, step_size, bc2_sqrt);
+      adam_element(pe.z, ge.z, me.z, ve.z, h, step_size, bc2_sqrt);
+      adam_element(pe.w, ge.w, me.w, ve.w, h, step_size, bc2_sqrt);
+      *reinterpret_cast<float4*>(p + e) = pe;
+      *reinterpret_cast<float4*>(m + e) = me;
+      *reinterpret_cast<float4*>(v + e) = ve;
+      if ((__float_as_uint(ge.x) | __float_as_uint(ge.y) | __float_as_uint(ge.z) | __float_as_uint(ge.w)) != 0u)
+        *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   for (long d = idx * (long)blockDim.x + threadIdx.x; d < n_rest; d += (long)n_dense * blockDim.x) {
     const long e = d < lo ? d : d + span;
     float pe = p[e], me = m[e], ve = v[e];

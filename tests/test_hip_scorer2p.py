@@ -50,6 +50,18 @@ def _same(a, b, what=''):
     assert not bool(bad.any()), f'{what}: {int(bad.sum())} users differ, first {int(bad.nonzero()[0])}: one-pass {i1[bad][0].tolist()} two-pass {i2[bad][0].tolist()}'
 
 
+def _near(got, ref, sc, off=0):
+    """Against the fp32 GEMM route: the same lists, except that two items whose fp32 scores differ by rounding only (the GEMM sums in
+    another order than the MFMA chain) may trade places — every listed item's fp32 score is within 2e-6 of the reference list's score at
+    that rank, and no excluded item is listed."""
+    (gv, gi), (rv, ri) = got, ref
+    n = rv.shape[0]
+    picked = torch.gather(sc[:n], 1, (gi[:n].long() - off).clamp_min(0))
+    assert bool((picked > -float('inf')).all()), 'an excluded item was listed'
+    assert bool(((picked - rv).abs() <= 2e-6 * rv.abs().clamp_min(1.0)).all()), 'a listed item is not a top-k item of the fp32 route'
+    assert float((gi[:n].long() != ri.long() + off).float().mean()) < 0.01, 'more than 1 % of the positions differ from the fp32 route'
+
+
 @pytest.mark.parametrize('U,I,D,k,per,off', [(3000, 20000, 128, 20, 30, 0), (2500, 16384, 64, 10, 0, 0), (1100, 9000, 256, 20, 25, 5000),
                                              (40000, 30011, 128, 20, 50, 0), (9000, 12345, 256, 32, 10, 777), (777, 8192, 128, 1, 5, 0),
                                              (33000, 8700, 64, 20, 40, 100)])
@@ -69,7 +81,7 @@ def test_two_pass_scorer_equals_the_one_pass_kernel(U, I, D, k, per, off):
     if ex is not None:
         S().ops.mask_scores_(sc, users[:n], ex[0], ex[1], item_offset=off)
     rv, ri = S().ops.topk_rows(sc, k)
-    assert torch.equal(two[1][:n].long(), ri.long() + off)
+    _near((two[0][:n], two[1][:n]), (rv, ri), sc, off)
 
 
 def test_two_pass_scorer_with_massive_ties_and_degenerate_users():
@@ -117,3 +129,22 @@ def test_two_pass_scorer_at_the_bench_shapes():
         ex = _excl(U, off + I, 50, D, heavy=((17, 3345),))
         one, two = _both(u16, i16, 20, users, ex, off)
         _same(one, two, f'{U}x{I}x{D}')
+
+
+def test_both_scorer_routes_with_a_user_index_map():
+    """``u_idx`` maps the scored rows to rows of the exclusion CSR (an evaluation chunk of a split whose users are not 0 .. U - 1): both
+    routes read the exclusions of the mapped user, and agree with the fp32 route."""
+    g = torch.Generator().manual_seed(17)
+    U, I, D, k = 1500, 9000, 128, 10
+    n_all = 5000
+    u16 = (torch.randn(U, D, generator=g) / 8).half().to(DEV)
+    i16 = (torch.randn(I, D, generator=g) / 8).half().to(DEV)
+    ex = _excl(n_all, I, 40, 17, heavy=((4321, 2500),))
+    users = torch.randperm(n_all, generator=g)[:U].to(DEV)          # int64 user ids in scoring order
+    users[7] = 4321
+    one, two = _both(u16, i16, k, users, ex)
+    _same(one, two, 'u_idx')
+    sc = u16.float() @ i16.float().t()
+    S().ops.mask_scores_(sc, users, ex[0], ex[1])
+    rv, ri = S().ops.topk_rows(sc, k)
+    _near(two, (rv, ri), sc)
