@@ -9,6 +9,8 @@ import sibrar_amd as S
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = 'cuda:0'
+if os.environ.get('SPLIT_MIN_ROWS'):       # lab: row threshold of the bf16-split GEMM kernels (ops._SPLIT_MIN_ROWS)
+    S.ops._SPLIT_MIN_ROWS = int(os.environ['SPLIT_MIN_ROWS'])
 ds, net = bench.build(S, bench.C2, dev)
 loss = S.RecSampledSoftmaxLoss(n_items=ds.n_items, aggregator='mean', train_neg_strategy='uniform_recbole', neg_train=ds.n_negative_samples)
 trainer = S.Trainer(net, None, None, loss, bench._Conf(dev))
