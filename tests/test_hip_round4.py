@@ -301,3 +301,35 @@ def test_c4_five_deferred_steps_with_the_engines_sweep_against_torch_adamw(monke
     assert abs(float(got.double().sum()) - float(want.sum())) <= 1e-6 * float(want.abs().sum())
     assert abs(float(got.double().pow(2).sum()) - float(want.pow(2).sum())) <= 1e-6 * float(want.pow(2).sum())
     fused.close()
+
+
+# ---- e) BASELINE configs[4] end to end on one GPU ---------------------------------------------------------------------------------
+def test_c5_eight_item_shards_merged_equal_the_unsharded_pass():
+    """What the 8-GPU job of BASELINE configs[4] computes, rank by rank on one GPU: 200k items x 256 fp16 cut into eight shards of 25k
+    (parallel.item_shard), every shard scored with the fused kernel at its item_offset against the same users (a 20k-user chunk, 50
+    exclusions per user over the whole catalogue), the eight [U, 20] lists stacked as an all-gather would leave them and merged by
+    sbr_merge_topk — against ONE unsharded pass over the whole catalogue: the same lists bit for bit (both scorer routes)."""
+    from importlib import import_module
+    _lib = import_module(S().ops.__name__.rsplit('.', 1)[0] + '._lib')
+    g = torch.Generator().manual_seed(5)
+    U, I, D, k, W = 20_000, 200_000, 256, 20, 8
+    u16 = (torch.randn(U, D, generator=g) / 16).half().to(DEV)
+    i16 = (torch.randn(I, D, generator=g) / 16).half().to(DEV)
+    ex = _excl_csr(U, I, 50, 5)
+    users = torch.arange(U, device=DEV)
+    for route in (1, 2):
+        prev = S().ops.score_topk_route(route)
+        try:
+            full_v, full_i = S().ops.score_topk_f16(u16, i16, k, users, ex[0], ex[1])
+            vals = torch.empty(W, U, k, device=DEV, dtype=torch.float32)
+            idxs = torch.empty(W, U, k, device=DEV, dtype=torch.int32)
+            for r in range(W):
+                lo, hi = S().parallel.item_shard(I, r, W)
+                assert hi - lo == 25_000
+                vals[r], idxs[r] = S().ops.score_topk_f16(u16, i16[lo:hi].contiguous(), k, users, ex[0], ex[1], item_offset=lo)
+        finally:
+            S().ops.score_topk_route(prev)
+        out_v, out_i = torch.empty(U, k, device=DEV), torch.empty(U, k, device=DEV, dtype=torch.int32)
+        _lib.call('sbr_merge_topk', vals.data_ptr(), idxs.data_ptr(), W, U, k, out_v.data_ptr(), out_i.data_ptr(), _lib.stream())
+        assert torch.equal(out_i, full_i) and torch.equal(out_v, full_v), f'route {route}: sharded + merged differs from the unsharded pass'
+        assert bool((full_v[:, :-1] >= full_v[:, 1:]).all()) and int(full_i.min()) >= 0 and int(full_i.max()) < I
