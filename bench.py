@@ -567,7 +567,7 @@ C1_MODEL = {'shared_common_dim': 64, 'user': {'feature_name': 'user_embedding', 
 
 
 C1_TRAIN_STEPS = 300      # recorded batches both sides train on before the evaluation that is compared
-C1_GPU_RUNS, C1_CPU_RUNS = 5, 3
+C1_GPU_RUNS, C1_CPU_RUNS = 8, 3
 C1_SNAP = (1, 10, 100, 300)
 
 
