@@ -441,6 +441,28 @@ def _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm):
     return dt, sum(ts) / len(ts), sum(tb) / len(tb)
 
 
+def _time_two_pass(S, u16, i16, k, users, excl, lo, reps=8, warm=4):
+    """The same pass through the opt-in two-pass scorer (sbr_score_topk_f16_route(2); same lists bit for bit): HIP-event
+    time of the call's four launches, exclusion mask resident. None when the shape does not take that route."""
+    if i16.shape[0] < 8192:
+        return None
+    prev = S.ops.score_topk_route(2)
+    try:
+        holder = S.ops.ScorerExclusions()
+        for _ in range(warm):
+            S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo, exclusions=holder)
+        S.ops.KernelTimer.reset(True)
+        for _ in range(reps):
+            S.ops.score_topk_f16(u16, i16, k, users, excl[0], excl[1], item_offset=lo, exclusions=holder)
+        ts = [t for key, v in S.ops.KernelTimer.results().items() if key[0] == 'score_topk_f16' for t in v]
+        S.ops.KernelTimer.reset(False)
+    finally:
+        S.ops.score_topk_route(prev)
+    avg = sum(ts) / len(ts)
+    flops = 2.0 * u16.shape[0] * i16.shape[0] * u16.shape[1]
+    return {'avg_launch_ms': round(avg, 4), 'frac': round(flops / (avg * 1e-3) / 1e12 / PEAK_MFMA_F16, 4)}
+
+
 def scoring_roofline(n_users, n_items, D, k, avg_ms, traffic=None, traffic_source=None, kernel=None):
     flops = 2.0 * n_users * n_items * D
     achieved = flops / (avg_ms * 1e-3) / 1e12
@@ -461,13 +483,15 @@ def bench_scoring(S, ds, net, device, rank, world, k=20, reps=20, warm=8):
         u16 = S.ops.cast_f16(net.get_user_representations(users))
         excl = S.evaluation._csr_to_device(ds.user_sampling_matrix_train, device)
         dt, avg_ms, build_ms = _time_scorer(S, u16, i16, k, users, excl, lo, world, reps, warm)
+        two = _time_two_pass(S, u16, i16, k, users, excl, lo) if world == 1 else None
     tr, src = pmc_scorer_traffic(ds.n_users) if world == 1 else (None, None)
     return {'metric': 'full-catalogue scores/s (fused fp16 score+mask+top-20)', 'value': ds.n_users * ds.n_items / dt,
             'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3), 'users': ds.n_users, 'items': ds.n_items, 'dim': int(i16.shape[1]),
             'sharding': f'items/{world}', 'exclusions': int(excl[1].numel()),
             'exclusion_mask': 'resident in the scorer\'s layout (built once per split by the first evaluation; a call that also converts '
                               f'the CSR takes {build_ms:.3f} ms)', 'ms_per_call_with_mask_conversion': round(build_ms, 4),
-            'roofline': scoring_roofline(ds.n_users, hi - lo, int(i16.shape[1]), k, avg_ms, tr, src)}
+            'roofline': scoring_roofline(ds.n_users, hi - lo, int(i16.shape[1]), k, avg_ms, tr, src),
+            **({'two_pass_route': two} if two else {})}
 
 
 def bench_c5_shard(S, device, k=20, reps=12, warm=6):
@@ -486,7 +510,8 @@ def bench_c5_shard(S, device, k=20, reps=12, warm=6):
     users = torch.arange(U, device=device)
     with torch.no_grad():
         dt, avg_ms, build_ms = _time_scorer(S, u16, i16, k, users, excl, 0, 1, reps, warm)
-    return {'workload': 'BASELINE configs[4], one of eight item shards: 100k users x 25k items x 256 fp16, 50 exclusions per user, top-20',
+        two = _time_two_pass(S, u16, i16, k, users, excl, 0)
+    return {'two_pass_route': two, 'workload': 'BASELINE configs[4], one of eight item shards: 100k users x 25k items x 256 fp16, 50 exclusions per user, top-20',
             'value': round(U * I / dt, 1), 'unit': 'scores/s', 'ms_per_pass': round(dt * 1e3, 3),
             'ms_per_call_with_mask_conversion': round(build_ms, 4),
             'roofline': scoring_roofline(U, I, D, k, avg_ms, *pmc_scorer_traffic(U, '_c5'))}
